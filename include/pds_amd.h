@@ -1,0 +1,190 @@
+/*
+ * pds_amd.h -- C ABI of the MI355X (gfx950) STFT filter-bank feature library.
+ *
+ * This is the drop-in boundary for ONE hot path of sdrobert/pydrobert-speech:
+ *   ShortTimeFourierTransformFrameComputer.compute_full   (reference compute.py:574-607,
+ *   per-frame worker _compute_frame compute.py:388-460) and the two post-processors
+ *   Deltas.apply (post.py:462-491) and Standardize/CMVN.apply (post.py:250-305).
+ *
+ * The reference is pure Python; it has no FFI of its own.  The entry points below are
+ * what a ctypes binding inside the reference would bind (INTEGRATION.md shows the stub).
+ * Conventions:
+ *   - plain C types only; every `d_*` pointer is a DEVICE pointer owned by the caller;
+ *   - every call that launches work takes the hipStream_t to launch on as `void *stream`
+ *     (NULL = the default stream) and never synchronises, allocates or frees;
+ *   - a plan owns device copies of its tables; plans are immutable after creation and may
+ *     be shared between host threads and streams;
+ *   - return value 0 = success, negative = error; pds_last_error() returns a thread-local
+ *     human-readable message for the last failure on the calling thread.
+ */
+#ifndef PDS_AMD_H
+#define PDS_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PDS_OK 0
+#define PDS_ERR_INVALID -1 /* bad argument / unsupported configuration */
+#define PDS_ERR_HIP -2     /* a HIP runtime call failed                  */
+
+/* library version, major * 10000 + minor * 100 + patch */
+int32_t pds_version(void);
+/* message describing the last error on this thread ("" if none) */
+const char *pds_last_error(void);
+/* number of visible HIP devices (0 when there is none; never fails) */
+int32_t pds_device_count(void);
+
+/* ---------------------------------------------------------------------------------
+ * STFT filter-bank plan: everything ShortTimeFourierTransformFrameComputer.__init__
+ * (reference compute.py:290-362) derives from its configuration.
+ * --------------------------------------------------------------------------------- */
+typedef struct pds_stft_desc {
+  int32_t frame_length;   /* L: samples per frame            (compute.py:332)          */
+  int32_t frame_shift;    /* S: samples between frames       (compute.py:305)          */
+  int32_t dft_size;       /* N >= L: DFT length              (compute.py:344-347)      */
+  int32_t pad_left;       /* left reflection: 0 causal, L/2-S/2 kaldi, (L+1)/2-1 else
+                             (compute.py:582-587)                                       */
+  int32_t num_filts;      /* F: rows of the bin-weight table                           */
+  int32_t nnz;            /* entries of the bin-weight table                           */
+  int32_t use_power;      /* 1: sum |X|^2 * w, 0: sum |X| * w (compute.py:221-226,348) */
+  int32_t use_log;        /* 1: log(max(., log_floor))       (compute.py:396,458)      */
+  int32_t include_energy; /* 1: column 0 = frame energy      (compute.py:392-398)      */
+  int32_t reserved;       /* must be 0                                                 */
+  double log_floor;       /* config.LOG_FLOOR_VALUE snapshot (config.py:52)            */
+} pds_stft_desc;
+
+typedef struct pds_stft_plan pds_stft_plan;
+
+/*
+ * window : host, double[L]                      (compute.py:343)
+ * row_ptr: host, int32[F + 1]  CSR row starts   -- the per-filter loop compute.py:416-460
+ * col    : host, int32[nnz]    half-spectrum bin of each entry, 0 <= col <= N/2,
+ *                              already folded the way the reference walks the spectrum
+ *                              (compute.py:423-455)
+ * val    : host, double[nnz]   weight = (2 if bank.is_real) * sum |H_f[k]|^p over the taps
+ *                              k that land on that bin (p = 2 if use_power else 1)
+ * Replaces: the tables `_window`, `_filt_start_idxs`, `_truncated_filts` (compute.py:352-359).
+ */
+int32_t pds_stft_plan_create(const pds_stft_desc *desc, const double *window,
+                             const int32_t *row_ptr, const int32_t *col, const double *val,
+                             pds_stft_plan **plan_out);
+void pds_stft_plan_destroy(pds_stft_plan *plan);
+
+/* coefficients per frame: F + include_energy (compute.py:216-218) */
+int32_t pds_stft_num_coeffs(const pds_stft_plan *plan);
+/* frames compute_full yields for a signal of n samples: 0 if n < L/2 + 1, else
+ * (n + S/2) / S (compute.py:580-581, 596) */
+int64_t pds_stft_num_frames(const pds_stft_plan *plan, int64_t n);
+/* which kernel family the plan dispatches to for float32 input: 1 = fused LDS/register
+ * FFT kernel (power-of-two N it is instantiated for), 0 = generic direct-DFT kernel */
+int32_t pds_stft_plan_kernel_kind(const pds_stft_plan *plan);
+
+/*
+ * Batched compute_full (compute.py:574-607) over B utterances packed in one buffer.
+ *
+ * d_signal   : device, T[...]       all utterances, utterance b at d_signal[d_offsets[b]]
+ * d_offsets  : device, int64[B]
+ * d_lengths  : device, int64[B]     samples of utterance b (reflection is about its ends)
+ * d_nframes  : device, int64[B]     frames to emit for b (pds_stft_num_frames for
+ *                                   compute_full; the streaming host logic passes the
+ *                                   count of completed frames, compute.py:480, 552-556)
+ * d_row_off  : device, int64[B]     first output row of utterance b
+ * max_frames : max over b of d_nframes[b] (sizes the launch grid; host knows it)
+ * pad_left   : left reflection to use for this call, or -1 for the plan's
+ * d_out      : device, T[rows * out_stride]  row r, coefficient c at r * out_stride + c
+ * out_stride : >= num_coeffs (lets a caller leave room for Deltas in the same rows)
+ *
+ * Frame t of utterance b, sample j:  i = t*S - pad_left + j, reflected symmetrically
+ * into [0, n) (numpy.pad(..., "symmetric"), compute.py:600).
+ */
+int32_t pds_stft_batch_f32(const pds_stft_plan *plan, const float *d_signal,
+                           const int64_t *d_offsets, const int64_t *d_lengths,
+                           const int64_t *d_nframes, const int64_t *d_row_off, int32_t B,
+                           int64_t max_frames, int32_t pad_left, float *d_out,
+                           int64_t out_stride, void *stream);
+/* float64 signals -> float64 features, float64 arithmetic throughout (the reference's
+ * internal precision, compute.py:403-414); always the generic kernel */
+int32_t pds_stft_batch_f64(const pds_stft_plan *plan, const double *d_signal,
+                           const int64_t *d_offsets, const int64_t *d_lengths,
+                           const int64_t *d_nframes, const int64_t *d_row_off, int32_t B,
+                           int64_t max_frames, int32_t pad_left, double *d_out,
+                           int64_t out_stride, void *stream);
+/* float32 input through the generic direct-DFT kernel regardless of N (cross-check of
+ * the fused kernel; also what non-power-of-two N uses) */
+int32_t pds_stft_batch_f32_generic(const pds_stft_plan *plan, const float *d_signal,
+                                   const int64_t *d_offsets, const int64_t *d_lengths,
+                                   const int64_t *d_nframes, const int64_t *d_row_off,
+                                   int32_t B, int64_t max_frames, int32_t pad_left,
+                                   float *d_out, int64_t out_stride, void *stream);
+
+/* ---------------------------------------------------------------------------------
+ * Deltas.apply (reference post.py:462-491): correlation along a "time" axis of a
+ * tensor viewed as [outer, time, inner], float64 accumulation, result cast back.
+ *
+ * d_in     : device, T[outer * time * inner]
+ * d_filts  : device, double[sum(filt_len)]   the filters of post.py:455-460, order 1..K,
+ *                                            concatenated
+ * d_filt_off: device, int32[K + 1]           start of each filter in d_filts
+ * edge_clamp: 1 = index clip(t + j, 0, time - 1) ("edge" padding, post.py:447);
+ *             0 = the caller already padded `time` by max_off on both sides of every
+ *                 slice (any other numpy.pad mode) and `time` is the unpadded length
+ * Output element (k, o, t, i), k = 0..K (k = 0 copies the input), is written to
+ *   d_out[k*out_sk + o*out_so + t*out_st + i*out_si]
+ * so one call can write the concatenated or the stacked layout of post.py:488-491.
+ * --------------------------------------------------------------------------------- */
+int32_t pds_deltas_f32(const float *d_in, int64_t outer, int64_t time, int64_t inner,
+                       const double *d_filts, const int32_t *d_filt_off, int32_t K,
+                       int32_t edge_clamp, int32_t max_off, float *d_out, int64_t out_sk,
+                       int64_t out_so, int64_t out_st, int64_t out_si, void *stream);
+int32_t pds_deltas_f64(const double *d_in, int64_t outer, int64_t time, int64_t inner,
+                       const double *d_filts, const int32_t *d_filt_off, int32_t K,
+                       int32_t edge_clamp, int32_t max_off, double *d_out, int64_t out_sk,
+                       int64_t out_so, int64_t out_st, int64_t out_si, void *stream);
+/* ragged batch of [time_b, inner] feature matrices stored row-wise in one buffer (the
+ * layout pds_stft_batch writes): utterance b occupies rows d_row_off[b] .. + d_nrows[b];
+ * deltas never cross an utterance boundary.  in/out strides are per row. */
+int32_t pds_deltas_rows_f32(const float *d_in, int64_t in_stride, const int64_t *d_row_off,
+                            const int64_t *d_nrows, int32_t B, int64_t max_rows,
+                            int32_t inner, const double *d_filts, const int32_t *d_filt_off,
+                            int32_t K, float *d_out, int64_t out_stride, void *stream);
+
+/* ---------------------------------------------------------------------------------
+ * Standardize / CMVN (reference post.py:193-212 accumulate, 250-295 apply) on a tensor
+ * viewed as [outer, coeff, inner]; statistics are over outer x inner per coefficient.
+ * --------------------------------------------------------------------------------- */
+/* d_stats: device, double[2 * C]: sum x (first C) and sum x^2 (next C); overwritten.
+ * d_scratch: device, double[pds_cmvn_scratch_len(C, inner)]; sums are formed in a fixed
+ * order (two-stage), so results are bitwise reproducible */
+int64_t pds_cmvn_scratch_len(int64_t coeff, int64_t inner);
+int32_t pds_cmvn_stats_f32(const float *d_in, int64_t outer, int64_t coeff, int64_t inner,
+                           double *d_stats, double *d_scratch, void *stream);
+int32_t pds_cmvn_stats_f64(const double *d_in, int64_t outer, int64_t coeff, int64_t inner,
+                           double *d_stats, double *d_scratch, void *stream);
+/* out[o, c, i] = in[o, c, i] * d_scale[c] - d_shift[c]   (post.py:293-294), float64 out */
+int32_t pds_cmvn_apply_f32(const float *d_in, int64_t outer, int64_t coeff, int64_t inner,
+                           const double *d_scale, const double *d_shift, double *d_out,
+                           void *stream);
+int32_t pds_cmvn_apply_f64(const double *d_in, int64_t outer, int64_t coeff, int64_t inner,
+                           const double *d_scale, const double *d_shift, double *d_out,
+                           void *stream);
+/* per-utterance ("local", post.py:278-281) CMVN over the ragged row layout: one pass
+ * of statistics, one of normalisation; variance within 1e-8 of 0 is replaced by 1
+ * (post.py:283-286) and counted in *d_zero_var (device int32, may be NULL).
+ * d_out is float64 like the reference's, or float32 with the _f32out variant. */
+int32_t pds_cmvn_rows_f32(const float *d_in, int64_t in_stride, const int64_t *d_row_off,
+                          const int64_t *d_nrows, int32_t B, int32_t coeff, int32_t norm_var,
+                          double *d_stats /* [B][2][coeff] scratch+result */,
+                          double *d_out, int64_t out_stride, int32_t *d_zero_var,
+                          void *stream);
+int32_t pds_cmvn_rows_f32out(const float *d_in, int64_t in_stride, const int64_t *d_row_off,
+                             const int64_t *d_nrows, int32_t B, int32_t coeff,
+                             int32_t norm_var, double *d_stats, float *d_out,
+                             int64_t out_stride, int32_t *d_zero_var, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PDS_AMD_H */

@@ -1,0 +1,140 @@
+"""ctypes binding of ``libpds_amd.so`` (C ABI: ``include/pds_amd.h``).
+
+There is deliberately no fallback: if the shared library is missing or a compute call
+is made without a HIP device, an exception is raised.  Nothing in this package computes
+features on the CPU.
+"""
+import ctypes
+import os
+from ctypes import POINTER, Structure, c_char_p, c_double, c_int32, c_int64, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libpds_amd.so")
+
+PDS_OK = 0
+
+
+class NativeError(RuntimeError):
+    """A call into libpds_amd.so failed"""
+
+
+class StftDesc(Structure):
+    # mirrors pds_stft_desc (include/pds_amd.h)
+    _fields_ = [
+        ("frame_length", c_int32),
+        ("frame_shift", c_int32),
+        ("dft_size", c_int32),
+        ("pad_left", c_int32),
+        ("num_filts", c_int32),
+        ("nnz", c_int32),
+        ("use_power", c_int32),
+        ("use_log", c_int32),
+        ("include_energy", c_int32),
+        ("reserved", c_int32),
+        ("log_floor", c_double),
+    ]
+
+
+_BATCH_ARGS = [
+    c_void_p,  # plan
+    c_void_p,  # d_signal
+    c_void_p,  # d_offsets
+    c_void_p,  # d_lengths
+    c_void_p,  # d_nframes
+    c_void_p,  # d_row_off
+    c_int32,  # B
+    c_int64,  # max_frames
+    c_int32,  # pad_left
+    c_void_p,  # d_out
+    c_int64,  # out_stride
+    c_void_p,  # stream
+]
+
+_DELTAS_ARGS = [
+    c_void_p, c_int64, c_int64, c_int64,  # d_in, outer, time, inner
+    c_void_p, c_void_p, c_int32,  # d_filts, d_filt_off, K
+    c_int32, c_int32,  # edge_clamp, max_off
+    c_void_p, c_int64, c_int64, c_int64, c_int64,  # d_out, sk, so, st, si
+    c_void_p,  # stream
+]
+
+_CMVN_ROWS_ARGS = [
+    c_void_p, c_int64, c_void_p, c_void_p, c_int32, c_int32, c_int32,
+    c_void_p, c_void_p, c_int64, c_void_p, c_void_p,
+]
+
+# name -> (restype, argtypes); every symbol include/pds_amd.h declares
+SIGNATURES = {
+    "pds_version": (c_int32, []),
+    "pds_last_error": (c_char_p, []),
+    "pds_device_count": (c_int32, []),
+    "pds_stft_plan_create": (
+        c_int32,
+        [POINTER(StftDesc), c_void_p, c_void_p, c_void_p, c_void_p, POINTER(c_void_p)],
+    ),
+    "pds_stft_plan_destroy": (None, [c_void_p]),
+    "pds_stft_num_coeffs": (c_int32, [c_void_p]),
+    "pds_stft_num_frames": (c_int64, [c_void_p, c_int64]),
+    "pds_stft_plan_kernel_kind": (c_int32, [c_void_p]),
+    "pds_stft_batch_f32": (c_int32, _BATCH_ARGS),
+    "pds_stft_batch_f64": (c_int32, _BATCH_ARGS),
+    "pds_stft_batch_f32_generic": (c_int32, _BATCH_ARGS),
+    "pds_deltas_f32": (c_int32, _DELTAS_ARGS),
+    "pds_deltas_f64": (c_int32, _DELTAS_ARGS),
+    "pds_deltas_rows_f32": (
+        c_int32,
+        [c_void_p, c_int64, c_void_p, c_void_p, c_int32, c_int64, c_int32, c_void_p,
+         c_void_p, c_int32, c_void_p, c_int64, c_void_p],
+    ),
+    "pds_cmvn_scratch_len": (c_int64, [c_int64, c_int64]),
+    "pds_cmvn_stats_f32": (c_int32, [c_void_p, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_void_p]),
+    "pds_cmvn_stats_f64": (c_int32, [c_void_p, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_void_p]),
+    "pds_cmvn_apply_f32": (c_int32, [c_void_p, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "pds_cmvn_apply_f64": (c_int32, [c_void_p, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "pds_cmvn_rows_f32": (c_int32, _CMVN_ROWS_ARGS),
+    "pds_cmvn_rows_f32out": (c_int32, _CMVN_ROWS_ARGS),
+}
+
+_lib = None
+
+
+def lib() -> ctypes.CDLL:
+    """The loaded library; raises :class:`NativeError` if it has not been built"""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise NativeError(
+                f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; "
+                "g.build()'` or `make -C pydrobert-speech_amd/csrc` (there is no CPU fallback)"
+            )
+        loaded = ctypes.CDLL(LIB_PATH)
+        for name, (restype, argtypes) in SIGNATURES.items():
+            fn = getattr(loaded, name)  # AttributeError if the .so is stale
+            fn.restype = restype
+            fn.argtypes = argtypes
+        _lib = loaded
+    return _lib
+
+
+def last_error() -> str:
+    return lib().pds_last_error().decode("utf-8", "replace")
+
+
+def check(rc: int, what: str) -> None:
+    if rc != PDS_OK:
+        msg = last_error()
+        if rc == -1:
+            raise ValueError(f"{what}: {msg}")
+        raise NativeError(f"{what}: {msg} (code {rc})")
+
+
+def require_device():
+    """torch with a visible HIP device, or an exception -- never a CPU path"""
+    import torch
+
+    if not torch.cuda.is_available():
+        raise NativeError(
+            "no HIP device is visible: this package computes features on an MI355X only "
+            "(no CPU fallback); the CPU restatement in oracle/ is test infrastructure"
+        )
+    return torch

@@ -1,0 +1,93 @@
+// Internal declarations shared by the translation units of libpds_amd.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <string>
+
+#include "../../include/pds_amd.h"
+
+namespace pds {
+
+void set_error(const std::string &msg);
+int32_t hip_fail(hipError_t err, const char *what);
+
+#define PDS_HIP(call)                                       \
+  do {                                                      \
+    hipError_t _e = (call);                                 \
+    if (_e != hipSuccess) return pds::hip_fail(_e, #call);  \
+  } while (0)
+
+// Tables of the fused kernel (stft_fast.hip); owned by the plan.
+struct FastTables {
+  int kind = 0;               // 0 = not available for this plan
+  int n1 = 0, n2 = 0;         // N = n1 * n2: in-lane real DFT size x lanes per frame
+  float *d_window = nullptr;  // [n2][n1] window, zero padded, in lane order
+  float *d_twiddle = nullptr; // inter-stage twiddles in lane order
+  int32_t *d_runs = nullptr;  // filter runs over the kernel's own bin order
+  float *d_wval = nullptr;    // weights in run order
+  int32_t *d_row_ptr = nullptr;
+  int32_t n_slots = 0;        // power slots per frame in LDS
+};
+
+}  // namespace pds
+
+struct pds_stft_plan {
+  pds_stft_desc d;
+  int device = 0;
+  int num_bins = 0;  // N/2 + 1 (even N) or (N+1)/2 (odd N): len(rfft)
+  // generic kernel tables
+  float *d_window_f32 = nullptr;
+  double *d_window_f64 = nullptr;
+  int32_t *d_row_ptr = nullptr;
+  int32_t *d_col = nullptr;
+  float *d_val_f32 = nullptr;
+  double *d_val_f64 = nullptr;
+  float2 *d_tw_f32 = nullptr;   // (cos, sin)(2 pi j / N), j in [0, N)
+  double2 *d_tw_f64 = nullptr;
+  pds::FastTables fast;
+};
+
+namespace pds {
+
+struct BatchArgs {
+  const void *d_signal;
+  const int64_t *d_offsets, *d_lengths, *d_nframes, *d_row_off;
+  int32_t B;
+  int64_t max_frames;
+  int32_t pad_left;
+  void *d_out;
+  int64_t out_stride;
+  hipStream_t stream;
+};
+
+// stft_generic.hip
+int32_t launch_stft_generic_f32(const pds_stft_plan *plan, const BatchArgs &a);
+int32_t launch_stft_generic_f64(const pds_stft_plan *plan, const BatchArgs &a);
+// stft_fast.hip
+int32_t fast_tables_create(pds_stft_plan *plan, const double *window, const int32_t *row_ptr,
+                           const int32_t *col, const double *val);
+void fast_tables_destroy(pds_stft_plan *plan);
+int32_t launch_stft_fast_f32(const pds_stft_plan *plan, const BatchArgs &a);
+
+// host helper: upload a host array
+template <typename T>
+int32_t upload(T **dst, const T *src, size_t count) {
+  *dst = nullptr;
+  if (count == 0) return PDS_OK;
+  PDS_HIP(hipMalloc((void **)dst, count * sizeof(T)));
+  PDS_HIP(hipMemcpy(*dst, src, count * sizeof(T), hipMemcpyHostToDevice));
+  return PDS_OK;
+}
+
+// symmetric reflection of index i into [0, n): numpy.pad(..., "symmetric") for any
+// pad width (reference compute.py:600)
+__device__ __forceinline__ int64_t reflect_index(int64_t i, int64_t n) {
+  if (i >= 0 && i < n) return i;
+  const int64_t period = 2 * n;
+  int64_t m = i % period;
+  if (m < 0) m += period;
+  return m < n ? m : period - 1 - m;
+}
+
+}  // namespace pds

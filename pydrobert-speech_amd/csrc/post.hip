@@ -1,0 +1,353 @@
+// Post-processor kernels: Deltas (reference post.py:462-491) and Standardize / CMVN
+// (post.py:193-212, 250-295).  Both are streaming, HBM-bound element-wise/stencil work;
+// accumulation is float64 as in the reference.
+#include "pds_internal.h"
+
+namespace pds {
+
+static int32_t invalid_post(const char *msg) {
+  set_error(msg);
+  return PDS_ERR_INVALID;
+}
+
+// ------------------------------------------------------------------ Deltas ---------
+
+// one thread per input element (o, t, i); writes the K + 1 outputs of that element
+template <typename T>
+__global__ __launch_bounds__(256) void deltas_kernel(
+    const T *__restrict__ in, int64_t outer, int64_t time, int64_t inner,
+    const double *__restrict__ filts, const int32_t *__restrict__ filt_off, int K,
+    int edge_clamp, int max_off, T *__restrict__ out, int64_t sk, int64_t so, int64_t st,
+    int64_t si) {
+  const int64_t total = outer * time * inner;
+  const int64_t in_time = edge_clamp ? time : time + 2 * (int64_t)max_off;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+       e += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t i = e % inner;
+    const int64_t t = (e / inner) % time;
+    const int64_t o = e / (inner * time);
+    const T *col = in + o * in_time * inner + i;
+    T *dst = out + o * so + t * st + i * si;
+    const int64_t tc = edge_clamp ? t : t + max_off;
+    dst[0] = col[tc * inner];
+    for (int k = 1; k <= K; ++k) {
+      const int lo = filt_off[k - 1], len = filt_off[k] - lo;
+      const int M = (len - 1) / 2;
+      double acc = 0.0;
+      for (int j = 0; j < len; ++j) {
+        int64_t tt = tc + j - M;
+        if (edge_clamp) tt = tt < 0 ? 0 : (tt >= time ? time - 1 : tt);
+        acc += filts[lo + j] * (double)col[tt * inner];
+      }
+      dst[k * sk] = (T)acc;
+    }
+  }
+}
+
+template <typename T>
+static int32_t launch_deltas(const T *d_in, int64_t outer, int64_t time, int64_t inner,
+                             const double *d_filts, const int32_t *d_filt_off, int32_t K,
+                             int32_t edge_clamp, int32_t max_off, T *d_out, int64_t sk,
+                             int64_t so, int64_t st, int64_t si, void *stream) {
+  if (outer < 0 || time < 0 || inner < 0 || K < 0 || max_off < 0)
+    return invalid_post("deltas: negative size");
+  const int64_t total = outer * time * inner;
+  if (total == 0) return PDS_OK;
+  if (!d_in || !d_out || (K > 0 && (!d_filts || !d_filt_off)))
+    return invalid_post("deltas: null pointer");
+  const int64_t blocks = (total + 255) / 256;
+  const unsigned grid = (unsigned)(blocks < 65536 * 4 ? blocks : 65536 * 4);
+  hipLaunchKernelGGL(deltas_kernel<T>, dim3(grid), dim3(256), 0, (hipStream_t)stream, d_in,
+                     outer, time, inner, d_filts, d_filt_off, K, edge_clamp, max_off, d_out, sk,
+                     so, st, si);
+  PDS_HIP(hipGetLastError());
+  return PDS_OK;
+}
+
+// ragged rows: grid (row tiles, utterance); thread = (row in tile, coefficient)
+__global__ __launch_bounds__(256) void deltas_rows_kernel(
+    const float *__restrict__ in, int64_t in_stride, const int64_t *__restrict__ row_off,
+    const int64_t *__restrict__ nrows, int inner, const double *__restrict__ filts,
+    const int32_t *__restrict__ filt_off, int K, float *__restrict__ out, int64_t out_stride,
+    int rows_per_block) {
+  const int b = blockIdx.y;
+  const int64_t T = nrows[b];
+  const int64_t t0 = (int64_t)blockIdx.x * rows_per_block;
+  if (t0 >= T) return;
+  const float *src = in + row_off[b] * in_stride;
+  float *dst = out + row_off[b] * out_stride;
+  const int items = rows_per_block * inner;
+  for (int e = threadIdx.x; e < items; e += blockDim.x) {
+    const int64_t t = t0 + e / inner;
+    const int i = e % inner;
+    if (t >= T) break;
+    dst[t * out_stride + i] = src[t * in_stride + i];
+    for (int k = 1; k <= K; ++k) {
+      const int lo = filt_off[k - 1], len = filt_off[k] - lo;
+      const int M = (len - 1) / 2;
+      double acc = 0.0;
+      for (int j = 0; j < len; ++j) {
+        int64_t tt = t + j - M;
+        tt = tt < 0 ? 0 : (tt >= T ? T - 1 : tt);
+        acc += filts[lo + j] * (double)src[tt * in_stride + i];
+      }
+      dst[t * out_stride + (int64_t)k * inner + i] = (float)acc;
+    }
+  }
+}
+
+// ------------------------------------------------------------------ CMVN -----------
+
+constexpr int kStatSlabs = 128;  // partial-sum slabs over `outer` (deterministic two-stage sum)
+
+// stage 1: column q = c * inner + i; 64 columns x 4 row phases per block
+template <typename T>
+__global__ __launch_bounds__(256) void cmvn_partial_kernel(const T *__restrict__ in,
+                                                           int64_t outer, int64_t Q,
+                                                           double *__restrict__ partial) {
+  __shared__ double red[2][4][64];
+  const int lane = threadIdx.x & 63, phase = threadIdx.x >> 6;
+  const int64_t q = (int64_t)blockIdx.y * 64 + lane;
+  const int64_t slab = (outer + gridDim.x - 1) / gridDim.x;
+  const int64_t o0 = (int64_t)blockIdx.x * slab;
+  const int64_t o1 = o0 + slab < outer ? o0 + slab : outer;
+  double s1 = 0.0, s2 = 0.0;
+  if (q < Q)
+    for (int64_t o = o0 + phase; o < o1; o += 4) {
+      const double v = (double)in[o * Q + q];
+      s1 += v;
+      s2 += v * v;
+    }
+  red[0][phase][lane] = s1;
+  red[1][phase][lane] = s2;
+  __syncthreads();
+  if (phase == 0 && q < Q) {
+    s1 = (red[0][0][lane] + red[0][1][lane]) + (red[0][2][lane] + red[0][3][lane]);
+    s2 = (red[1][0][lane] + red[1][1][lane]) + (red[1][2][lane] + red[1][3][lane]);
+    partial[((int64_t)blockIdx.x * Q + q) * 2 + 0] = s1;
+    partial[((int64_t)blockIdx.x * Q + q) * 2 + 1] = s2;
+  }
+}
+
+// stage 2: one thread per coefficient sums slabs and the `inner` columns, fixed order
+__global__ void cmvn_final_kernel(const double *__restrict__ partial, int slabs, int64_t C,
+                                  int64_t inner, double *__restrict__ stats) {
+  const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const int64_t Q = C * inner;
+  double s1 = 0.0, s2 = 0.0;
+  for (int g = 0; g < slabs; ++g)
+    for (int64_t i = 0; i < inner; ++i) {
+      s1 += partial[((int64_t)g * Q + c * inner + i) * 2 + 0];
+      s2 += partial[((int64_t)g * Q + c * inner + i) * 2 + 1];
+    }
+  stats[c] = s1;
+  stats[C + c] = s2;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void cmvn_apply_kernel(const T *__restrict__ in,
+                                                         int64_t total, int64_t C,
+                                                         int64_t inner,
+                                                         const double *__restrict__ scale,
+                                                         const double *__restrict__ shift,
+                                                         double *__restrict__ out) {
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+       e += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t c = (e / inner) % C;
+    // x * scale - mean * scale, two roundings as in post.py:293-294
+    out[e] = (double)in[e] * scale[c] - shift[c];
+  }
+}
+
+static int slabs_for(int64_t outer) {
+  int64_t s = (outer + 63) / 64;
+  if (s < 1) s = 1;
+  return (int)(s < kStatSlabs ? s : kStatSlabs);
+}
+
+template <typename T>
+static int32_t launch_cmvn_stats(const T *d_in, int64_t outer, int64_t C, int64_t inner,
+                                 double *d_stats, double *d_scratch, void *stream) {
+  if (outer <= 0 || C <= 0 || inner <= 0) return invalid_post("cmvn_stats: empty tensor");
+  if (!d_in || !d_stats || !d_scratch) return invalid_post("cmvn_stats: null pointer");
+  const int64_t Q = C * inner;
+  const int slabs = slabs_for(outer);
+  const int64_t qblocks = (Q + 63) / 64;
+  if (qblocks > 65535) return invalid_post("cmvn_stats: coeff * inner too large");
+  hipLaunchKernelGGL(cmvn_partial_kernel<T>, dim3(slabs, (unsigned)qblocks), dim3(256), 0,
+                     (hipStream_t)stream, d_in, outer, Q, d_scratch);
+  hipLaunchKernelGGL(cmvn_final_kernel, dim3((unsigned)((C + 63) / 64)), dim3(64), 0,
+                     (hipStream_t)stream, d_scratch, slabs, C, inner, d_stats);
+  PDS_HIP(hipGetLastError());
+  return PDS_OK;
+}
+
+template <typename T>
+static int32_t launch_cmvn_apply(const T *d_in, int64_t outer, int64_t C, int64_t inner,
+                                 const double *d_scale, const double *d_shift, double *d_out,
+                                 void *stream) {
+  const int64_t total = outer * C * inner;
+  if (total <= 0) return invalid_post("cmvn_apply: empty tensor");
+  if (!d_in || !d_scale || !d_shift || !d_out) return invalid_post("cmvn_apply: null pointer");
+  const int64_t blocks = (total + 255) / 256;
+  const unsigned grid = (unsigned)(blocks < 65536 * 4 ? blocks : 65536 * 4);
+  hipLaunchKernelGGL(cmvn_apply_kernel<T>, dim3(grid), dim3(256), 0, (hipStream_t)stream, d_in,
+                     total, C, inner, d_scale, d_shift, d_out);
+  PDS_HIP(hipGetLastError());
+  return PDS_OK;
+}
+
+// per-utterance CMVN over ragged rows: one block per (utterance, 64-column chunk);
+// pass 1 statistics, pass 2 normalise (the rows are re-read from L2)
+template <typename OutT>
+__global__ __launch_bounds__(256) void cmvn_rows_kernel(
+    const float *__restrict__ in, int64_t in_stride, const int64_t *__restrict__ row_off,
+    const int64_t *__restrict__ nrows, int C, int norm_var, double *__restrict__ stats,
+    OutT *__restrict__ out, int64_t out_stride, int32_t *__restrict__ zero_var) {
+  __shared__ double red[2][4][64];
+  __shared__ double sc[64], sh[64];
+  const int b = blockIdx.y;
+  const int lane = threadIdx.x & 63, phase = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + lane;
+  const int64_t T = nrows[b];
+  if (T <= 0) return;
+  const float *src = in + row_off[b] * in_stride;
+  double s1 = 0.0, s2 = 0.0;
+  if (c < C)
+    for (int64_t t = phase; t < T; t += 4) {
+      const double v = (double)src[t * in_stride + c];
+      s1 += v;
+      s2 += v * v;
+    }
+  red[0][phase][lane] = s1;
+  red[1][phase][lane] = s2;
+  __syncthreads();
+  if (phase == 0 && c < C) {
+    s1 = (red[0][0][lane] + red[0][1][lane]) + (red[0][2][lane] + red[0][3][lane]);
+    s2 = (red[1][0][lane] + red[1][1][lane]) + (red[1][2][lane] + red[1][3][lane]);
+    stats[((int64_t)b * 2 + 0) * C + c] = s1;
+    stats[((int64_t)b * 2 + 1) * C + c] = s2;
+    const double mean = s1 / (double)T;
+    double scale = 1.0;
+    if (norm_var) {
+      double var = s2 / (double)T - mean * mean;
+      if (fabs(var) <= 1e-8) {  // numpy.isclose(var, 0) (post.py:283)
+        var = 1.0;
+        if (zero_var) atomicAdd(zero_var, 1);
+      }
+      scale = 1.0 / sqrt(var);
+    }
+    sc[lane] = scale;
+    sh[lane] = mean * scale;
+  }
+  __syncthreads();
+  if (c < C) {
+    OutT *dst = out + row_off[b] * out_stride;
+    const double scale = sc[lane], shift = sh[lane];
+    for (int64_t t = phase; t < T; t += 4)
+      dst[t * out_stride + c] = (OutT)((double)src[t * in_stride + c] * scale - shift);
+  }
+}
+
+template <typename OutT>
+static int32_t launch_cmvn_rows(const float *d_in, int64_t in_stride, const int64_t *d_row_off,
+                                const int64_t *d_nrows, int32_t B, int32_t C, int32_t norm_var,
+                                double *d_stats, OutT *d_out, int64_t out_stride,
+                                int32_t *d_zero_var, void *stream) {
+  if (B < 0 || C <= 0) return invalid_post("cmvn_rows: bad B / coeff");
+  if (B == 0) return PDS_OK;
+  if (B > 65535) return invalid_post("cmvn_rows: B > 65535");
+  if (!d_in || !d_row_off || !d_nrows || !d_stats || !d_out)
+    return invalid_post("cmvn_rows: null pointer");
+  hipLaunchKernelGGL(cmvn_rows_kernel<OutT>, dim3((unsigned)((C + 63) / 64), (unsigned)B),
+                     dim3(256), 0, (hipStream_t)stream, d_in, in_stride, d_row_off, d_nrows, C,
+                     norm_var, d_stats, d_out, out_stride, d_zero_var);
+  PDS_HIP(hipGetLastError());
+  return PDS_OK;
+}
+
+}  // namespace pds
+
+extern "C" {
+
+int32_t pds_deltas_f32(const float *d_in, int64_t outer, int64_t time, int64_t inner,
+                       const double *d_filts, const int32_t *d_filt_off, int32_t K,
+                       int32_t edge_clamp, int32_t max_off, float *d_out, int64_t out_sk,
+                       int64_t out_so, int64_t out_st, int64_t out_si, void *stream) {
+  return pds::launch_deltas<float>(d_in, outer, time, inner, d_filts, d_filt_off, K, edge_clamp,
+                                   max_off, d_out, out_sk, out_so, out_st, out_si, stream);
+}
+
+int32_t pds_deltas_f64(const double *d_in, int64_t outer, int64_t time, int64_t inner,
+                       const double *d_filts, const int32_t *d_filt_off, int32_t K,
+                       int32_t edge_clamp, int32_t max_off, double *d_out, int64_t out_sk,
+                       int64_t out_so, int64_t out_st, int64_t out_si, void *stream) {
+  return pds::launch_deltas<double>(d_in, outer, time, inner, d_filts, d_filt_off, K,
+                                    edge_clamp, max_off, d_out, out_sk, out_so, out_st, out_si,
+                                    stream);
+}
+
+int32_t pds_deltas_rows_f32(const float *d_in, int64_t in_stride, const int64_t *d_row_off,
+                            const int64_t *d_nrows, int32_t B, int64_t max_rows,
+                            int32_t inner, const double *d_filts, const int32_t *d_filt_off,
+                            int32_t K, float *d_out, int64_t out_stride, void *stream) {
+  if (B < 0 || max_rows < 0 || inner <= 0 || K < 0)
+    return pds::invalid_post("deltas_rows: bad size");
+  if (B == 0 || max_rows == 0) return PDS_OK;
+  if (B > 65535) return pds::invalid_post("deltas_rows: B > 65535");
+  if (!d_in || !d_row_off || !d_nrows || !d_out || (K > 0 && (!d_filts || !d_filt_off)))
+    return pds::invalid_post("deltas_rows: null pointer");
+  if (in_stride < inner || out_stride < (int64_t)(K + 1) * inner)
+    return pds::invalid_post("deltas_rows: stride too small");
+  int rows_per_block = 1024 / inner;
+  if (rows_per_block < 1) rows_per_block = 1;
+  if (rows_per_block > 64) rows_per_block = 64;
+  dim3 grid((unsigned)((max_rows + rows_per_block - 1) / rows_per_block), (unsigned)B);
+  hipLaunchKernelGGL(pds::deltas_rows_kernel, grid, dim3(256), 0, (hipStream_t)stream, d_in,
+                     in_stride, d_row_off, d_nrows, inner, d_filts, d_filt_off, K, d_out,
+                     out_stride, rows_per_block);
+  PDS_HIP(hipGetLastError());
+  return PDS_OK;
+}
+
+int64_t pds_cmvn_scratch_len(int64_t coeff, int64_t inner) {
+  return (int64_t)pds::kStatSlabs * coeff * inner * 2;
+}
+
+int32_t pds_cmvn_stats_f32(const float *d_in, int64_t outer, int64_t coeff, int64_t inner,
+                           double *d_stats, double *d_scratch, void *stream) {
+  return pds::launch_cmvn_stats<float>(d_in, outer, coeff, inner, d_stats, d_scratch, stream);
+}
+int32_t pds_cmvn_stats_f64(const double *d_in, int64_t outer, int64_t coeff, int64_t inner,
+                           double *d_stats, double *d_scratch, void *stream) {
+  return pds::launch_cmvn_stats<double>(d_in, outer, coeff, inner, d_stats, d_scratch, stream);
+}
+int32_t pds_cmvn_apply_f32(const float *d_in, int64_t outer, int64_t coeff, int64_t inner,
+                           const double *d_scale, const double *d_shift, double *d_out,
+                           void *stream) {
+  return pds::launch_cmvn_apply<float>(d_in, outer, coeff, inner, d_scale, d_shift, d_out,
+                                       stream);
+}
+int32_t pds_cmvn_apply_f64(const double *d_in, int64_t outer, int64_t coeff, int64_t inner,
+                           const double *d_scale, const double *d_shift, double *d_out,
+                           void *stream) {
+  return pds::launch_cmvn_apply<double>(d_in, outer, coeff, inner, d_scale, d_shift, d_out,
+                                        stream);
+}
+int32_t pds_cmvn_rows_f32(const float *d_in, int64_t in_stride, const int64_t *d_row_off,
+                          const int64_t *d_nrows, int32_t B, int32_t coeff, int32_t norm_var,
+                          double *d_stats, double *d_out, int64_t out_stride,
+                          int32_t *d_zero_var, void *stream) {
+  return pds::launch_cmvn_rows<double>(d_in, in_stride, d_row_off, d_nrows, B, coeff, norm_var,
+                                       d_stats, d_out, out_stride, d_zero_var, stream);
+}
+int32_t pds_cmvn_rows_f32out(const float *d_in, int64_t in_stride, const int64_t *d_row_off,
+                             const int64_t *d_nrows, int32_t B, int32_t coeff,
+                             int32_t norm_var, double *d_stats, float *d_out,
+                             int64_t out_stride, int32_t *d_zero_var, void *stream) {
+  return pds::launch_cmvn_rows<float>(d_in, in_stride, d_row_off, d_nrows, B, coeff, norm_var,
+                                      d_stats, d_out, out_stride, d_zero_var, stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,134 @@
+// Generic STFT filter-bank kernel: any DFT size N, float32 or float64, direct DFT.
+//
+// One wavefront per frame.  The frame is reflected/windowed into LDS, every lane
+// evaluates bins k = lane, lane + 64, ... as a dot product with a twiddle table, the
+// power (or magnitude) spectrum goes back to LDS and lanes walk the CSR rows of the
+// bin-weight table.  O(L * N/2) per frame -- this is the always-available path
+// (non-power-of-two N, float64 parity with the reference's float64 arithmetic,
+// cross-check of the fused kernel), not the fast one (stft_fast.hip).
+//
+// Follows _compute_frame (reference compute.py:388-460) and the framing of
+// compute_full (compute.py:574-607).
+#include "pds_internal.h"
+
+namespace pds {
+
+template <typename T>
+struct Tw;
+template <>
+struct Tw<float> {
+  using type = float2;
+};
+template <>
+struct Tw<double> {
+  using type = double2;
+};
+
+template <typename T>
+__device__ __forceinline__ T wave_sum(T v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+template <typename T, int FPB>
+__global__ __launch_bounds__(64 * FPB) void stft_generic_kernel(
+    const T *__restrict__ sig, const int64_t *__restrict__ offsets,
+    const int64_t *__restrict__ lengths, const int64_t *__restrict__ nframes,
+    const int64_t *__restrict__ row_off, const T *__restrict__ window,
+    const typename Tw<T>::type *__restrict__ tw, const int32_t *__restrict__ row_ptr,
+    const int32_t *__restrict__ col, const T *__restrict__ val, T *__restrict__ out,
+    int64_t out_stride, int L, int S, int N, int num_bins, int pad_left, int F, int use_power,
+    int use_log, int include_energy, T log_floor) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int b = blockIdx.y;
+  const int64_t nfr = nframes[b];
+  const int64_t t = (int64_t)blockIdx.x * FPB + wave;
+  if (t >= nfr) return;  // whole wave leaves; no block-level barrier is used below
+  const int64_t n = lengths[b];
+  const T *x = sig + offsets[b];
+  T *xw = reinterpret_cast<T *>(smem_raw) + (size_t)wave * (L + num_bins);
+  T *pw = xw + L;
+
+  // frame -> LDS (windowed); energy on the un-windowed samples (compute.py:392-393)
+  const int64_t start = t * S - pad_left;
+  T e = 0;
+  for (int j = lane; j < L; j += 64) {
+    const T s = x[reflect_index(start + j, n)];
+    e += s * s;
+    xw[j] = s * window[j];
+  }
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): this wave's LDS writes have landed
+
+  // direct DFT of the L non-zero samples (zero padding to N contributes nothing)
+  for (int k = lane; k < num_bins; k += 64) {
+    T re = 0, im = 0;
+    int idx = 0;  // (j * k) mod N
+    for (int j = 0; j < L; ++j) {
+      const typename Tw<T>::type w = tw[idx];
+      const T v = xw[j];
+      re += v * w.x;
+      im -= v * w.y;
+      idx += k;
+      if (idx >= N) idx -= N;
+    }
+    pw[k] = use_power ? re * re + im * im : sqrt(re * re + im * im);
+  }
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_s_waitcnt(0xc07f);
+
+  T *orow = out + (row_off[b] + t) * out_stride;
+  if (include_energy) {
+    e = wave_sum(e) / (T)L;
+    if (!use_power) e = sqrt(e);
+    if (use_log) e = log(e > log_floor ? e : log_floor);
+    if (lane == 0) orow[0] = e;
+    orow += 1;
+  }
+  for (int f = lane; f < F; f += 64) {
+    T acc = 0;
+    for (int q = row_ptr[f]; q < row_ptr[f + 1]; ++q) acc += val[q] * pw[col[q]];
+    if (use_log) acc = log(acc > log_floor ? acc : log_floor);
+    orow[f] = acc;
+  }
+}
+
+template <typename T, int FPB>
+static int32_t launch_one(const pds_stft_plan *p, const BatchArgs &a, const T *window,
+                          const typename Tw<T>::type *tw, const T *val, size_t smem) {
+  dim3 grid((unsigned)((a.max_frames + FPB - 1) / FPB), (unsigned)a.B);
+  auto kern = stft_generic_kernel<T, FPB>;
+  if (smem > 64 * 1024)
+    PDS_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)smem));
+  hipLaunchKernelGGL(kern, grid, dim3(64 * FPB), smem, a.stream, (const T *)a.d_signal,
+                     a.d_offsets, a.d_lengths, a.d_nframes, a.d_row_off, window, tw,
+                     p->d_row_ptr, p->d_col, val, (T *)a.d_out, a.out_stride, p->d.frame_length,
+                     p->d.frame_shift, p->d.dft_size, p->num_bins, a.pad_left, p->d.num_filts,
+                     p->d.use_power, p->d.use_log, p->d.include_energy, (T)p->d.log_floor);
+  PDS_HIP(hipGetLastError());
+  return PDS_OK;
+}
+
+template <typename T>
+static int32_t launch_generic(const pds_stft_plan *p, const BatchArgs &a, const T *window,
+                              const typename Tw<T>::type *tw, const T *val) {
+  const size_t per_frame = (size_t)(p->d.frame_length + p->num_bins) * sizeof(T);
+  const size_t budget = 150 * 1024;
+  if (4 * per_frame <= budget) return launch_one<T, 4>(p, a, window, tw, val, 4 * per_frame);
+  if (per_frame <= budget) return launch_one<T, 1>(p, a, window, tw, val, per_frame);
+  set_error("stft_batch: frame_length + dft_size/2 too large for LDS");
+  return PDS_ERR_INVALID;
+}
+
+int32_t launch_stft_generic_f32(const pds_stft_plan *p, const BatchArgs &a) {
+  return launch_generic<float>(p, a, p->d_window_f32, p->d_tw_f32, p->d_val_f32);
+}
+
+int32_t launch_stft_generic_f64(const pds_stft_plan *p, const BatchArgs &a) {
+  return launch_generic<double>(p, a, p->d_window_f64, p->d_tw_f64, p->d_val_f64);
+}
+
+}  // namespace pds
