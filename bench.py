@@ -1,0 +1,242 @@
+#!/usr/bin/env python3
+"""Benchmark of the STFT filter-bank hot path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+
+One "step" = one pass of the batched compute_full kernel over one batch of synthetic
+utterances already resident in HBM.  Workload at N = 1: BASELINE.json configs[1]
+(1024 x 10 s, 16 kHz float32, 40 triangular mel filters, Hann, 25/10 ms, log power).
+For N > 1 the driver launches one rank per GPU with torch.distributed.run; utterances
+shard across ranks (each rank a full 1024-utterance batch: weak scaling), no data-path
+collective in the timed region.  A second, separately reported region adds the RCCL
+gather of the feature matrices.
+
+Prints ONE JSON line (rank 0) with the fields the driver expects plus `roofline` (HBM
+bound, algorithmic bytes / kernel time measured with events on the launch stream) and
+`cpu_baseline` (the oracle's vectorised numpy restatement timed on host cores, a bounded
+sample; rank 0, N = 1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip-level parameters)
+
+WORKLOADS = {
+    # name: (config, samples per utterance, utterances per GPU)
+    "fbank40_16k_25_10_b1024x10s": (
+        {"name": "stft", "bank": {"name": "tri", "scaling_function": "mel", "num_filts": 40},
+         "frame_length_ms": 25, "frame_shift_ms": 10, "window_function": "hanning",
+         "use_power": True},
+        160000, 1024,
+    ),
+}
+
+
+def _cpu_worker(args):
+    """Times the oracle on `count` utterances; runs in a spawned process (numpy only)"""
+    cfg_tables, n, count, seed = args
+    import numpy as np
+
+    from oracle import stft_oracle as orc
+
+    p = orc.StftParams(**cfg_tables)
+    rng = np.random.default_rng(seed)
+    x = (3000.0 * rng.standard_normal(n)).astype(np.float32)
+    orc.compute_full(x[: n // 8], p)  # warm caches / imports
+    t0 = time.perf_counter()
+    frames = 0
+    for _ in range(count):
+        frames += orc.compute_full(x, p).shape[0]
+    return frames, time.perf_counter() - t0
+
+
+def cpu_baseline(comp, n, budget_s=12.0):
+    """Oracle throughput on the host: one process per core, bounded sample"""
+    import multiprocessing as mp
+
+    import numpy as np
+
+    os.environ.setdefault("OMP_NUM_THREADS", "1")
+    os.environ.setdefault("OPENBLAS_NUM_THREADS", "1")
+    tables = dict(
+        frame_length=comp.frame_length, frame_shift=comp.frame_shift, dft_size=comp.dft_size,
+        window=np.asarray(comp._window), starts=list(comp._filt_start_idxs),
+        taps=[np.asarray(t) for t in comp._truncated_filts], is_real=comp.bank.is_real,
+        centered=comp.frame_style == "centered", kaldi_shift=comp.kaldi_shift,
+        include_energy=comp.includes_energy, use_power=bool(comp._power), use_log=bool(comp._log),
+    )
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    cores = max(1, min(cores, 32))
+    # ~130 k frames/s/core measured for this oracle => utterances per worker for ~budget_s
+    per_worker = max(2, int(budget_s * 100000 / comp.num_frames(n)))
+    ctx = mp.get_context("spawn")
+    t0 = time.perf_counter()
+    with ctx.Pool(cores) as pool:
+        res = pool.map(_cpu_worker, [(tables, n, per_worker, 1000 + i) for i in range(cores)])
+    wall = time.perf_counter() - t0
+    frames = sum(r[0] for r in res)
+    slowest = max(r[1] for r in res)
+    return {
+        "value": frames / slowest,
+        "unit": "frames/s",
+        "cores": cores,
+        "kind": "port",
+        "sample": f"{cores} procs x {per_worker} utterances x {n} samples "
+                  f"(oracle/stft_oracle.compute_full, vectorised numpy float64; {wall:.1f} s wall)",
+        "per_core": frames / slowest / cores,
+        "reference_python_loop_frames_per_s_per_core": 3650.0,  # BASELINE.md section 2 (authoring container)
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="fbank40_16k_25_10_b1024x10s")
+    ap.add_argument("--batch", type=int, default=None, help="utterances per GPU (default: workload's)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-gather", action="store_true")
+    ap.add_argument("--generic", action="store_true", help="force the direct-DFT kernel")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+        args.gpus = world
+
+    import numpy as np
+
+    import pydrobert_speech_amd as ps
+    from pydrobert_speech_amd.alias import alias_factory_subclass_from_arg
+
+    cfg, n, B = WORKLOADS[args.workload]
+    if args.batch:
+        B = args.batch
+    comp = alias_factory_subclass_from_arg(ps.compute.FrameComputer, cfg)
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(comp, n)  # before the GPU is touched by this process
+
+    import torch
+    import torch.distributed as dist
+
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    # synthetic batch: x = 3000 N(0,1), float32, seeded per rank; generated on the device
+    g = torch.Generator(device=dev).manual_seed(1234 + rank)
+    signal = torch.randn(B * n, generator=g, device=dev, dtype=torch.float32).mul_(3000.0)
+    layout = comp.prepare_layout(np.arange(B, dtype=np.int64) * n, np.full(B, n, dtype=np.int64), device=dev)
+    frames = layout.total_rows
+    out = torch.empty((frames, comp.num_coeffs), dtype=torch.float32, device=dev)
+
+    def step():
+        comp.launch(signal, layout, out=out, generic=args.generic)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    # timed region: exactly K steps, events on the launch stream give the kernel time
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    t0 = time.perf_counter()
+    for a, b in evs:
+        a.record()
+        step()
+        b.record()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    kernel_ms = [a.elapsed_time(b) for a, b in evs]
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    finite = bool(torch.isfinite(out).all().item())
+
+    gather = None
+    if world > 1 and not args.no_gather:
+        gathered = torch.empty((world * frames, comp.num_coeffs), dtype=torch.float32, device=dev)
+        for _ in range(2):
+            step()
+            dist.all_gather_into_tensor(gathered, out)
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+            dist.all_gather_into_tensor(gathered, out)
+        barrier()
+        t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el = float(t.item())
+        gather = {"value": world * frames * args.steps / el, "unit": "frames/s",
+                  "ms_per_step": 1e3 * el / args.steps,
+                  "collective": "all_gather_into_tensor (RCCL)",
+                  "bytes_per_rank": frames * comp.num_coeffs * 4}
+
+    if rank == 0:
+        bytes_per_frame = 4 * comp.frame_shift + 4 * comp.num_coeffs
+        k_avg_s = 1e-3 * float(np.mean(kernel_ms))
+        achieved = frames * bytes_per_frame / k_avg_s / 1e9
+        value = world * frames * args.steps / elapsed
+        line = {
+            "metric": "frames/s (whole node) + HBM-roofline %, 40-mel fbank 16kHz 25/10ms",
+            "value": value,
+            "unit": "frames/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": args.workload, "utterances_per_gpu": B, "samples_per_utterance": n,
+                "frames_per_gpu_per_step": frames, "num_coeffs": comp.num_coeffs,
+                "frame_length": comp.frame_length, "frame_shift": comp.frame_shift,
+                "dft_size": comp.dft_size, "parallelism": f"utterance-sharded x{world}",
+                "kernel": "generic-direct-dft" if (args.generic or not comp.kernel_kind) else "fused-fft",
+            },
+            "roofline": {
+                "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                "kernel_ms_avg": 1e3 * k_avg_s, "kernel_ms_min": float(np.min(kernel_ms)),
+                "algorithmic_bytes_per_frame": bytes_per_frame,
+                "frames_per_s_per_gpu_kernel_only": frames / k_avg_s,
+            },
+            "outputs_finite": finite,
+        }
+        if cpu is not None:
+            line["cpu_baseline"] = cpu
+        if gather is not None:
+            line["with_gather"] = gather
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -20,6 +20,7 @@ from .alias import AliasedFactory, alias_factory_subclass_from_arg
 from .filters import GammaWindow, HannWindow, LinearFilterBank, WindowFunction
 
 __all__ = [
+    "PackedLayout",
     "bin_weight_table",
     "fold_spectrum_index",
     "frame_by_frame_calculation",
@@ -158,6 +159,22 @@ def bin_weight_table(
     col = np.concatenate(cols) if cols else np.zeros(0, np.int32)
     val = np.concatenate(vals) if vals else np.zeros(0, np.float64)
     return np.asarray(row_ptr, dtype=np.int32), col.astype(np.int32), val.astype(np.float64)
+
+
+class PackedLayout:
+    """Geometry of a packed batch: where each utterance starts, how many frames it yields
+    and where its rows go.  Built by :func:`STFTFrameComputer.prepare_layout`."""
+
+    def __init__(self, B, extent, nframes, row_offsets, d_meta):
+        self.B = B
+        self.extent = extent  # samples of signal buffer the batch spans
+        self.nframes = nframes  # host int64[B]
+        self.row_offsets = row_offsets  # host int64[B + 1]
+        self.d_meta = d_meta  # device int64[4, B]: offsets, lengths, nframes, row offsets
+
+    @property
+    def total_rows(self) -> int:
+        return int(self.row_offsets[-1])
 
 
 class _NativePlan:
@@ -339,42 +356,14 @@ class ShortTimeFourierTransformFrameComputer(LinearFilterBankFrameComputer):
             self._plan = _NativePlan(desc, self._window, self._row_ptr, self._col, self._val)
         return self._plan
 
-    def compute_packed(
-        self,
-        signal,
-        offsets: Sequence[int],
-        lengths: Sequence[int],
-        nframes: Optional[Sequence[int]] = None,
-        pad_left: Optional[int] = None,
-        out=None,
-        out_stride: Optional[int] = None,
-        generic: bool = False,
-    ):
-        """Launch the batch kernel on utterances packed in one device tensor
+    def prepare_layout(self, offsets, lengths, nframes=None, device="cuda") -> "PackedLayout":
+        """Describe a packed batch once; reuse it for every launch with that geometry
 
-        Parameters
-        ----------
-        signal : torch.Tensor
-            1-D float32 or float64 tensor on a HIP device holding every utterance
-        offsets, lengths
-            Start and sample count of each utterance inside `signal` (host sequences)
-        nframes
-            Frames to emit per utterance; default :func:`num_frames` of each length
-        pad_left
-            Override of the left reflection (used by the streaming methods)
-        out : torch.Tensor, optional
-            Pre-allocated ``(total_rows, out_stride)`` output (same dtype as `signal`)
-        generic
-            Force the direct-DFT kernel for float32 input (cross-checks)
-
-        Returns
-        -------
-        feats : torch.Tensor of shape ``(total_rows, out_stride)``
-        row_offsets : numpy int64 array of length ``B + 1``
+        `offsets` / `lengths` (host sequences) locate each utterance in the packed signal
+        buffer; `nframes` defaults to :func:`num_frames` of each length.  The returned
+        object owns the small device-side index arrays the kernel reads.
         """
         torch = _native.require_device()
-        lib = _native.lib()
-        plan = self._native_plan()
         lengths = np.asarray(lengths, dtype=np.int64).reshape(-1)
         offsets = np.asarray(offsets, dtype=np.int64).reshape(-1)
         B = len(lengths)
@@ -384,67 +373,88 @@ class ShortTimeFourierTransformFrameComputer(LinearFilterBankFrameComputer):
             nframes = np.asarray(nframes, dtype=np.int64).reshape(-1)
         if len(offsets) != B or len(nframes) != B:
             raise ValueError("offsets, lengths and nframes must have the same length")
-        if not signal.is_cuda or signal.dim() != 1 or not signal.is_contiguous():
-            raise ValueError("signal must be a contiguous 1-D tensor on the GPU")
-        if B and (
-            offsets.min() < 0
-            or lengths.min() < 0
-            or (offsets + lengths).max() > signal.numel()
-        ):
-            raise ValueError("an utterance lies outside the signal buffer")
+        if B and (offsets.min() < 0 or lengths.min() < 0 or nframes.min() < 0):
+            raise ValueError("negative offset, length or frame count")
         if B and ((nframes > 0) & (lengths <= 0)).any():
             raise ValueError("cannot emit frames for an empty utterance")
+        row_offsets = np.zeros(B + 1, dtype=np.int64)
+        np.cumsum(nframes, out=row_offsets[1:])
+        meta = np.stack([offsets, lengths, nframes, row_offsets[:-1]]) if B else np.zeros((4, 0), np.int64)
+        return PackedLayout(
+            B=B,
+            extent=int((offsets + lengths).max()) if B else 0,
+            nframes=nframes,
+            row_offsets=row_offsets,
+            d_meta=torch.from_numpy(np.ascontiguousarray(meta)).to(device),
+        )
+
+    def launch(self, signal, layout: "PackedLayout", out=None, pad_left=None, generic=False):
+        """Queue the batch kernel for `layout` on the current stream; returns the output
+
+        `signal`: contiguous 1-D float32/float64 GPU tensor; `out`: optional
+        ``(>= total_rows, >= num_coeffs)`` tensor of the same dtype with unit column
+        stride (its row stride may be larger, e.g. to leave room for deltas).  Nothing
+        here synchronises or allocates besides `out` when it is not given.
+        """
+        torch = _native.require_device()
+        lib = _native.lib()
+        plan = self._native_plan()
+        if not signal.is_cuda or signal.dim() != 1 or not signal.is_contiguous():
+            raise ValueError("signal must be a contiguous 1-D tensor on the GPU")
+        if layout.extent > signal.numel():
+            raise ValueError("an utterance lies outside the signal buffer")
         if signal.dtype == torch.float32:
             fn = lib.pds_stft_batch_f32_generic if generic else lib.pds_stft_batch_f32
         elif signal.dtype == torch.float64:
             fn = lib.pds_stft_batch_f64
         else:
             raise TypeError("signal must be float32 or float64")
-        row_offsets = np.zeros(B + 1, dtype=np.int64)
-        np.cumsum(nframes, out=row_offsets[1:])
-        total = int(row_offsets[-1])
-        width = self.num_coeffs if out_stride is None else int(out_stride)
+        total = layout.total_rows
         if out is None:
-            out = torch.empty((total, width), dtype=signal.dtype, device=signal.device)
+            out = torch.empty((total, self.num_coeffs), dtype=signal.dtype, device=signal.device)
         elif (
             out.dtype != signal.dtype
             or out.dim() != 2
             or out.shape[0] < total
+            or out.shape[1] < self.num_coeffs
             or out.stride(1) != 1
-            or out.stride(0) < self.num_coeffs
         ):
             raise ValueError("out has the wrong dtype, shape or strides")
-        else:
-            width = out.stride(0)
         if total == 0:
-            return out, row_offsets
+            return out
         stream = torch.cuda.current_stream(signal.device).cuda_stream
         pad = -1 if pad_left is None else int(pad_left)
+        meta = layout.d_meta
         with torch.cuda.device(signal.device):
-            for lo in range(0, B, _MAX_UTTS_PER_CALL):
-                hi = min(B, lo + _MAX_UTTS_PER_CALL)
-                meta = np.stack(
-                    [offsets[lo:hi], lengths[lo:hi], nframes[lo:hi], row_offsets[lo:hi]]
-                )
-                d_meta = torch.from_numpy(meta).to(signal.device)
+            for lo in range(0, layout.B, _MAX_UTTS_PER_CALL):
+                hi = min(layout.B, lo + _MAX_UTTS_PER_CALL)
                 rc = fn(
                     plan.handle,
                     signal.data_ptr(),
-                    d_meta[0].data_ptr(),
-                    d_meta[1].data_ptr(),
-                    d_meta[2].data_ptr(),
-                    d_meta[3].data_ptr(),
+                    meta[0, lo:].data_ptr(),
+                    meta[1, lo:].data_ptr(),
+                    meta[2, lo:].data_ptr(),
+                    meta[3, lo:].data_ptr(),
                     hi - lo,
-                    int(nframes[lo:hi].max()),
+                    int(layout.nframes[lo:hi].max()),
                     pad,
                     out.data_ptr(),
-                    width,
+                    out.stride(0),
                     stream,
                 )
                 _native.check(rc, "pds_stft_batch")
-                # d_meta is freed by torch's stream-ordered caching allocator only
-                # after the kernel queued above has consumed it (same stream)
-        return out, row_offsets
+        return out
+
+    def compute_packed(self, signal, offsets, lengths, nframes=None, pad_left=None, out=None,
+                       generic=False):
+        """:func:`prepare_layout` + :func:`launch` in one call
+
+        Returns ``(feats, row_offsets)``: the ``(total_rows, num_coeffs)`` GPU tensor and
+        the ``B + 1`` host row offsets of the utterances inside it.
+        """
+        layout = self.prepare_layout(offsets, lengths, nframes, device=signal.device)
+        feats = self.launch(signal, layout, out=out, pad_left=pad_left, generic=generic)
+        return feats, layout.row_offsets
 
     @staticmethod
     def _compute_dtype(dtype) -> np.dtype:

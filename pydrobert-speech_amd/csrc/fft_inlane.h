@@ -1,0 +1,186 @@
+// In-lane (register-resident) FFT building blocks for the fused STFT kernel.
+//
+// Everything here is straight-line code after inlining: sizes, strides and twiddle
+// factors are template parameters, so arrays are scalarised into VGPRs and every twiddle
+// is an instruction literal.  Radix-2 decimation in time with the trivial twiddles
+// (1, -i, (1-i)/sqrt2, (-1-i)/sqrt2) specialised, which gives split-radix-like operation
+// counts (N = 16 complex: 144 adds + 24 multiplies).
+//
+// Compiles for host and device so the host unit test (tests/test_fft_inlane.py) can
+// exercise the same templates.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <type_traits>
+
+#include "twiddle_consts.h"
+
+#define PDS_HD __host__ __device__ __forceinline__
+
+namespace pds {
+namespace inl {
+
+template <int I>
+using Int = std::integral_constant<int, I>;
+
+template <int B, int E, typename F>
+PDS_HD void static_for(F &&f) {
+  if constexpr (B < E) {
+    f(Int<B>{});
+    static_for<B + 1, E>(f);
+  }
+}
+
+// e^{-2 pi i K / N}; N must divide 256
+template <int N, int K>
+struct Tw {
+  static_assert(256 % N == 0, "twiddle table covers divisors of 256");
+  static constexpr int idx = (((K % N) + N) % N) * (256 / N);
+  static constexpr float re = (float)kCos256[idx];
+  static constexpr float im = (float)(-kSin256[idx]);
+};
+
+// (yr + i yi) = (xr + i xi) * e^{-2 pi i K / N}
+template <int N, int K>
+PDS_HD void mul_tw(float xr, float xi, float &yr, float &yi) {
+  constexpr int k = ((K % N) + N) % N;
+  constexpr float h = 0.70710678118654752440f;
+  if constexpr (k == 0) {
+    yr = xr;
+    yi = xi;
+  } else if constexpr (4 * k == N) {  // -i
+    yr = xi;
+    yi = -xr;
+  } else if constexpr (2 * k == N) {  // -1
+    yr = -xr;
+    yi = -xi;
+  } else if constexpr (4 * k == 3 * N) {  // +i
+    yr = -xi;
+    yi = xr;
+  } else if constexpr (8 * k == N) {  // (1 - i) / sqrt 2
+    yr = (xr + xi) * h;
+    yi = (xi - xr) * h;
+  } else if constexpr (8 * k == 3 * N) {  // (-1 - i) / sqrt 2
+    yr = (xi - xr) * h;
+    yi = -(xr + xi) * h;
+  } else {
+    constexpr float c = Tw<N, k>::re, s = Tw<N, k>::im;
+    yr = xr * c - xi * s;
+    yi = xr * s + xi * c;
+  }
+}
+
+// Complex FFT of N points read with stride IS from (xr, xi); natural-order output.
+template <int N, int IS>
+struct CFFT {
+  static PDS_HD void run(const float *xr, const float *xi, float *yr, float *yi) {
+    constexpr int H = N / 2;
+    float er[H], ei[H], qr[H], qi[H];
+    CFFT<H, 2 * IS>::run(xr, xi, er, ei);
+    CFFT<H, 2 * IS>::run(xr + IS, xi + IS, qr, qi);
+    static_for<0, H>([&](auto kk) {
+      constexpr int k = decltype(kk)::value;
+      float tr, ti;
+      mul_tw<N, k>(qr[k], qi[k], tr, ti);
+      yr[k] = er[k] + tr;
+      yi[k] = ei[k] + ti;
+      yr[k + H] = er[k] - tr;
+      yi[k + H] = ei[k] - ti;
+    });
+  }
+};
+
+template <int IS>
+struct CFFT<1, IS> {
+  static PDS_HD void run(const float *xr, const float *xi, float *yr, float *yi) {
+    yr[0] = xr[0];
+    yi[0] = xi[0];
+  }
+};
+
+template <int IS>
+struct CFFT<2, IS> {
+  static PDS_HD void run(const float *xr, const float *xi, float *yr, float *yi) {
+    const float ar = xr[0], ai = xi[0], br = xr[IS], bi = xi[IS];
+    yr[0] = ar + br;
+    yi[0] = ai + bi;
+    yr[1] = ar - br;
+    yi[1] = ai - bi;
+  }
+};
+
+template <int IS>
+struct CFFT<4, IS> {
+  static PDS_HD void run(const float *xr, const float *xi, float *yr, float *yi) {
+    const float ar = xr[0] + xr[2 * IS], ai = xi[0] + xi[2 * IS];
+    const float br = xr[0] - xr[2 * IS], bi = xi[0] - xi[2 * IS];
+    const float cr = xr[IS] + xr[3 * IS], ci = xi[IS] + xi[3 * IS];
+    const float dr = xr[IS] - xr[3 * IS], di = xi[IS] - xi[3 * IS];
+    yr[0] = ar + cr;
+    yi[0] = ai + ci;
+    yr[2] = ar - cr;
+    yi[2] = ai - ci;
+    yr[1] = br + di;  // b - i d
+    yi[1] = bi - dr;
+    yr[3] = br - di;  // b + i d
+    yi[3] = bi + dr;
+  }
+};
+
+// DFT of M real points a[0..M): produces
+//   even_sum = sum a[2m], odd_sum = sum a[2m+1]     (so A[0] = even + odd, A[M/2] = even - odd)
+//   (Ar, Ai)[k] for k = 1 .. M/2 - 1, SCALED: 2 * A[k], except k = M/4 which is A[k] itself.
+// The factor is undone by the caller's next twiddle multiply (its table is pre-scaled), which
+// saves the halving of the even/odd split.  A[k] = sum_n a[n] e^{-2 pi i n k / M}.
+template <int M>
+PDS_HD void rdft_scaled(const float *a, float &even_sum, float &odd_sum, float *Ar, float *Ai) {
+  constexpr int H = M / 2;
+  float zr[H], zi[H];
+  CFFT<H, 2>::run(a, a + 1, zr, zi);  // z[m] = a[2m] + i a[2m+1]
+  even_sum = zr[0];
+  odd_sum = zi[0];
+  if constexpr (H >= 2) {
+    Ar[H / 2] = zr[H / 2];  // A[M/4] = conj(Z[H/2])
+    Ai[H / 2] = -zi[H / 2];
+  }
+  static_for<1, H / 2>([&](auto kk) {
+    constexpr int k = decltype(kk)::value;
+    // Fe = (Z[k] + conj Z[H-k]) / 2, Fo = (Z[k] - conj Z[H-k]) / (2i); A[k] = Fe + W_M^k Fo,
+    // A[H-k] = conj(Fe - W_M^k Fo).  Everything below carries the factor 2.
+    const float sr = zr[k] + zr[H - k], si = zi[k] - zi[H - k];
+    const float dr = zr[k] - zr[H - k], di = zi[k] + zi[H - k];
+    constexpr float wr = Tw<M, k>::re, wi = Tw<M, k>::im;
+    const float tr = wr * di + wi * dr;  // W * (di - i dr)
+    const float ti = wi * di - wr * dr;
+    Ar[k] = sr + tr;
+    Ai[k] = si + ti;
+    Ar[H - k] = sr - tr;
+    Ai[H - k] = ti - si;
+  });
+}
+
+// DFT of M real points stored as z[m] = c[2m] + i c[2m+1] ALREADY transformed: given
+// Y = FFT_{M/2}(z), writes |A[m]|^2 (or |A[m]|) for m = 0 .. M/2, UNSCALED.
+template <int M, typename Emit>
+PDS_HD void rdft_finish_power(const float *Yr, const float *Yi, Emit &&emit) {
+  constexpr int H = M / 2;
+  {
+    const float a0 = Yr[0] + Yi[0], aH = Yr[0] - Yi[0];
+    emit(Int<0>{}, a0, 0.0f);
+    emit(Int<H>{}, aH, 0.0f);
+  }
+  if constexpr (H >= 2) emit(Int<H / 2>{}, Yr[H / 2], -Yi[H / 2]);
+  static_for<1, H / 2>([&](auto kk) {
+    constexpr int k = decltype(kk)::value;
+    const float sr = Yr[k] + Yr[H - k], si = Yi[k] - Yi[H - k];
+    const float dr = Yr[k] - Yr[H - k], di = Yi[k] + Yi[H - k];
+    constexpr float wr = Tw<M, k>::re, wi = Tw<M, k>::im;
+    const float tr = wr * di + wi * dr;
+    const float ti = wi * di - wr * dr;
+    emit(Int<k>{}, 0.5f * (sr + tr), 0.5f * (si + ti));
+    emit(Int<H - k>{}, 0.5f * (sr - tr), 0.5f * (ti - si));
+  });
+}
+
+}  // namespace inl
+}  // namespace pds

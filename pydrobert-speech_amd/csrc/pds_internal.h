@@ -20,14 +20,14 @@ int32_t hip_fail(hipError_t err, const char *what);
 
 // Tables of the fused kernel (stft_fast.hip); owned by the plan.
 struct FastTables {
-  int kind = 0;               // 0 = not available for this plan
+  int kind = 0;               // 0 = not available for this plan, else the DFT size served
   int n1 = 0, n2 = 0;         // N = n1 * n2: in-lane real DFT size x lanes per frame
-  float *d_window = nullptr;  // [n2][n1] window, zero padded, in lane order
-  float *d_twiddle = nullptr; // inter-stage twiddles in lane order
-  int32_t *d_runs = nullptr;  // filter runs over the kernel's own bin order
-  float *d_wval = nullptr;    // weights in run order
-  int32_t *d_row_ptr = nullptr;
-  int32_t n_slots = 0;        // power slots per frame in LDS
+  int num_cus = 0;            // persistent grid size
+  float *d_window = nullptr;  // [n2][n1] window in lane order, zero padded
+  float *d_twiddle = nullptr; // [n2][n1/2] (re, im) inter-stage twiddles in lane order
+  int32_t *d_order = nullptr; // [F] filters sorted by row length (longest first)
+  int32_t *d_toff = nullptr;  // [nnz] LDS offset (bin * row stride) of each table entry
+  float *d_wval = nullptr;    // [nnz] weights
 };
 
 }  // namespace pds

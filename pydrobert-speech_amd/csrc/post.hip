@@ -37,7 +37,9 @@ __global__ __launch_bounds__(256) void deltas_kernel(
       for (int j = 0; j < len; ++j) {
         int64_t tt = tc + j - M;
         if (edge_clamp) tt = tt < 0 ? 0 : (tt >= time ? time - 1 : tt);
-        acc += filts[lo + j] * (double)col[tt * inner];
+        // multiply and add rounded separately (no FMA): bit-identical to numpy.correlate's
+        // sequential sum, which matters when the result is cast to an integer dtype
+        acc = __dadd_rn(acc, __dmul_rn(filts[lo + j], (double)col[tt * inner]));
       }
       dst[k * sk] = (T)acc;
     }
@@ -89,7 +91,7 @@ __global__ __launch_bounds__(256) void deltas_rows_kernel(
       for (int j = 0; j < len; ++j) {
         int64_t tt = t + j - M;
         tt = tt < 0 ? 0 : (tt >= T ? T - 1 : tt);
-        acc += filts[lo + j] * (double)src[tt * in_stride + i];
+        acc = __dadd_rn(acc, __dmul_rn(filts[lo + j], (double)src[tt * in_stride + i]));
       }
       dst[t * out_stride + (int64_t)k * inner + i] = (float)acc;
     }
@@ -156,7 +158,7 @@ __global__ __launch_bounds__(256) void cmvn_apply_kernel(const T *__restrict__ i
        e += (int64_t)gridDim.x * blockDim.x) {
     const int64_t c = (e / inner) % C;
     // x * scale - mean * scale, two roundings as in post.py:293-294
-    out[e] = (double)in[e] * scale[c] - shift[c];
+    out[e] = __dsub_rn(__dmul_rn((double)in[e], scale[c]), shift[c]);
   }
 }
 
@@ -246,7 +248,7 @@ __global__ __launch_bounds__(256) void cmvn_rows_kernel(
     OutT *dst = out + row_off[b] * out_stride;
     const double scale = sc[lane], shift = sh[lane];
     for (int64_t t = phase; t < T; t += 4)
-      dst[t * out_stride + c] = (OutT)((double)src[t * in_stride + c] * scale - shift);
+      dst[t * out_stride + c] = (OutT)__dsub_rn(__dmul_rn((double)src[t * in_stride + c], scale), shift);
   }
 }
 

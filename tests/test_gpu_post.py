@@ -1,0 +1,143 @@
+"""Parity of the Deltas / Standardize kernels with reference outputs and the oracle"""
+import numpy as np
+import pytest
+
+from pydrobert_speech_amd.post import Deltas, Standardize
+from oracle import stft_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+def test_deltas_match_reference_outputs(golden_post):
+    for T in (1, 3, 50):
+        x = golden_post[f"deltas/in/T{T}"]
+        for nd in (1, 2):
+            for W in (2, 3):
+                got = Deltas(nd, context_window=W, target_axis=1).apply(x, axis=0)
+                want = golden_post[f"deltas/out/T{T}/n{nd}/w{W}"]
+                assert got.dtype == want.dtype and got.shape == want.shape
+                assert np.allclose(got, want, rtol=1e-6, atol=1e-6)
+    x = golden_post["deltas/in/nd3"]
+    got = Deltas(2, concatenate=False, target_axis=0).apply(x, axis=1)
+    assert got.dtype == np.float64
+    assert np.allclose(got, golden_post["deltas/out/nd3/axis1_stack0"], rtol=1e-12, atol=1e-12)
+    got = Deltas(1, target_axis=1).apply(x, axis=2)
+    assert np.allclose(got, golden_post["deltas/out/nd3/axis2_cat1"], rtol=1e-12, atol=1e-12)
+    xr = x[:, :, :1].repeat(3, 2)[:4]
+    got = Deltas(2, target_axis=-1, pad_mode="reflect").apply(xr, axis=1)
+    assert np.allclose(got, golden_post["deltas/out/nd3/axis0_reflect"], rtol=1e-12, atol=1e-12)
+
+
+@pytest.mark.parametrize("concatenate", [True, False])
+@pytest.mark.parametrize("num_deltas", range(4))
+def test_delta_shapes(concatenate, num_deltas):
+    # reference tests/test_post.py:111-133
+    rng = np.random.default_rng(0)
+    for buff in (rng.random(10), rng.random((2, 5)), rng.random((3, 6, 4)), rng.random((5, 4, 0, 0, 1))):
+        for target_axis in range(buff.ndim + 1 - int(concatenate)):
+            d = Deltas(num_deltas, concatenate=concatenate, target_axis=target_axis)
+            for axis in range(buff.ndim):
+                shape = list(buff.shape)
+                if concatenate:
+                    shape[target_axis] *= num_deltas + 1
+                else:
+                    shape.insert(target_axis, num_deltas + 1)
+                assert d.apply(buff, axis=axis).shape == tuple(shape)
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32, np.int32, np.int16])
+@pytest.mark.parametrize("window", range(1, 6))
+@pytest.mark.parametrize("num_deltas", range(5))
+def test_deltas_vs_oracle(dtype, window, num_deltas):
+    # reference tests/test_post.py:179-193 (Kaldi comparison), oracle in Kaldi's role
+    rng = np.random.default_rng(window * 10 + num_deltas)
+    for shape in ((1, 3), (3, 1), (20, 50)):
+        buff = (rng.random(shape) * 100).astype(dtype)
+        got = Deltas(num_deltas, context_window=window, target_axis=1).apply(buff, axis=0)
+        want = orc.deltas(buff, axis=0, num_deltas=num_deltas, context_window=window, target_axis=1)
+        assert got.dtype == want.dtype and np.allclose(got, want)
+
+
+def test_cmvn_matches_reference_outputs(golden_post):
+    x = golden_post["cmvn/in"]
+    for got, key in (
+        (Standardize().apply(x, axis=-1), "local"),
+        (Standardize(norm_var=False).apply(x, axis=1), "local_novar"),
+        (Standardize().apply(x.T.copy(), axis=0), "local_axis0"),
+    ):
+        assert got.dtype == np.float64
+        assert np.allclose(got, golden_post[f"cmvn/out/{key}"], rtol=1e-10, atol=1e-10), key
+    st = Standardize()
+    st.accumulate(x[:20])
+    st.accumulate(x[20:45])
+    st.accumulate(x[45])
+    assert np.allclose(st._stats, golden_post["cmvn/stats"], rtol=1e-12)
+    assert np.allclose(st.apply(x), golden_post["cmvn/out/global"], rtol=1e-10, atol=1e-10)
+    assert np.allclose(st.apply(x[3]), golden_post["cmvn/out/global_vec"], rtol=1e-10, atol=1e-10)
+    x3 = golden_post["cmvn/in3"]
+    assert np.allclose(Standardize().apply(x3, axis=1), golden_post["cmvn/out/in3_axis1"], rtol=1e-10, atol=1e-10)
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32, np.int32, np.int16])
+@pytest.mark.parametrize("norm_var", [True, False])
+def test_standardize_local_properties(norm_var, dtype):
+    # reference tests/test_post.py:16-52
+    rng = np.random.default_rng(3)
+    for shape in ((100, 1), (5, 5), (10, 4, 3)):
+        buff = (rng.random(shape) * 37 + 4).astype(dtype)
+        stand = Standardize(norm_var=norm_var)
+        for axis in range(buff.ndim):
+            other = tuple(i for i in range(buff.ndim) if i != axis)
+            if sum(buff.shape[i] for i in other) == len(other):
+                continue
+            b2 = buff.copy()
+            s1 = [0] * buff.ndim
+            s2 = [-1] * buff.ndim
+            s1[axis] = s2[axis] = slice(None)
+            b2[tuple(s1)] = b2[tuple(s2)] - 1
+            out = stand.apply(b2, axis=axis)
+            assert out.dtype == np.float64
+            assert np.allclose(out.mean(axis=other), 0)
+            if norm_var:
+                assert np.allclose(out.var(axis=other), 1)
+
+
+def test_standardize_errors_and_warnings():
+    with pytest.raises(ValueError, match="Cannot apply to empty array"):
+        Standardize().apply(np.zeros((0, 3)))
+    with pytest.raises(ValueError, match="Cannot accumulate from empty array"):
+        Standardize().accumulate(np.zeros((0, 3)))
+    with pytest.raises(ValueError, match="Unable to standardize the variance"):
+        Standardize().apply(np.ones(4))
+    with pytest.warns(UserWarning, match="Standardizing a single vector to 0"):
+        assert not Standardize(norm_var=False).apply(np.ones(4)).any()
+    with pytest.warns(UserWarning, match="0 variance encountered"):
+        out = Standardize().apply(np.ones((5, 2)))
+    assert not out.any()
+    st = Standardize()
+    st.accumulate(np.ones((4, 3)))
+    with pytest.raises(ValueError, match="Expected feature vector of length 3; got 2"):
+        st.apply(np.ones((4, 2)))
+
+
+def test_rows_variants_match_per_utterance_apply():
+    import torch
+
+    rng = np.random.default_rng(9)
+    lens = [1, 7, 250, 3, 1000]
+    rows = np.concatenate([[0], np.cumsum(lens)])
+    feats = (rng.standard_normal((rows[-1], 24)) * 3 + 1).astype("f4")
+    d_feats = torch.from_numpy(feats).cuda()
+    got = Deltas(2).apply_rows(d_feats, rows).cpu().numpy()
+    for b in range(len(lens)):
+        want = orc.deltas(feats[rows[b] : rows[b + 1]], axis=0, num_deltas=2, target_axis=1)
+        assert np.allclose(got[rows[b] : rows[b + 1]], want, rtol=1e-6, atol=1e-6)
+    lens2 = [2, 7, 250, 3, 1000]
+    rows2 = np.concatenate([[0], np.cumsum(lens2)])
+    feats2 = (rng.standard_normal((rows2[-1], 70)) * 3 + 1).astype("f4")
+    st = Standardize()
+    got = st.apply_rows(torch.from_numpy(feats2).cuda(), rows2).cpu().numpy()
+    assert got.dtype == np.float64
+    for b in range(len(lens2)):
+        want = orc.cmvn_local(feats2[rows2[b] : rows2[b + 1]], axis=-1)
+        assert np.allclose(got[rows2[b] : rows2[b + 1]], want, rtol=1e-9, atol=1e-9)
