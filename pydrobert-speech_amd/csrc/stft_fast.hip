@@ -25,6 +25,8 @@
 // (compute.py:388-460), float32 arithmetic (the north star's 1e-4 tolerance).
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
+#include <cstring>
 #include <vector>
 
 #include "fft_inlane.h"
@@ -46,6 +48,12 @@ struct FastParams {
   int L, S, pad_left, F, include_energy, use_power, use_log;
   float log_floor, inv_L;
   int tiles_per_utt, n_items;
+  // wave-independent variant (stft_wave_kernel): filter table in ELL form, see below
+  const float2 *ell;       // [ell_steps][N2] (LDS byte offset of the bin as int bits, weight)
+  const int32_t *ell_filt; // [ell_slots][N2] filter handled by lane j in slot s, or -1
+  const int32_t *ell_end;  // [ell_slots] end step of each slot (cumulative)
+  int ell_steps, ell_slots;
+  int chunks_per_utt, num_utts;
 };
 
 template <int N1, int N2, int WAVES>
@@ -68,9 +76,19 @@ struct FastGeom {
   static_assert(H1 % N2 == 0 && CPL >= 1, "columns must split evenly over the lane group");
   static_assert(FPB % (WAVES * GROUPS) == 0 && ITERS >= 1, "batch must split evenly over waves");
   static_assert(N2 <= 32 && (RS * 8) % 16 == 0, "exchange rows must stay 16-byte aligned");
+  static_assert(EXCH_F2_PER_WAVE * 2 >= 64 * N1, "edge-frame gather reuses the exchange area");
 };
 
-template <int N1, int N2, int WAVES>
+// v_mul_legacy_f32: IEEE multiply except that 0 * x = 0 for every x (NaN and Inf included)
+__device__ __forceinline__ float mul_legacy(float x, float y) {
+  float z;
+  asm("v_mul_legacy_f32 %0, %1, %2" : "=v"(z) : "v"(x), "v"(y));
+  return z;
+}
+
+// NROWS = rows of N2 samples a frame spans, ceil(L / N2), a compile-time constant so that the
+// zero-padded tail of the DFT input is literal zeros (the in-lane FFT is pruned accordingly).
+template <int N1, int N2, int WAVES, int NROWS>
 __global__ __launch_bounds__(WAVES * 64) void stft_fast_kernel(const FastParams p) {
   using G = FastGeom<N1, N2, WAVES>;
   constexpr int N = G::N, H1 = G::H1, FS = G::FS, RS = G::RS, NB = G::NB;
@@ -83,10 +101,10 @@ __global__ __launch_bounds__(WAVES * 64) void stft_fast_kernel(const FastParams 
   float2 *exch = reinterpret_cast<float2 *>(stage) + wave * G::EXCH_F2_PER_WAVE + g * H1 * RS;
 
   // per-lane constants, loop invariant: window slice and inter-stage twiddles
-  float win[N1];
+  float win[NROWS];
   float twr[H1], twi[H1];
 #pragma unroll
-  for (int n1 = 0; n1 < N1; ++n1) win[n1] = p.win_lane[r * N1 + n1];
+  for (int n1 = 0; n1 < NROWS; ++n1) win[n1] = p.win_lane[r * N1 + n1];
 #pragma unroll
   for (int k1 = 1; k1 < H1; ++k1) {
     const float2 t = p.tw_lane[r * H1 + k1];
@@ -94,6 +112,7 @@ __global__ __launch_bounds__(WAVES * 64) void stft_fast_kernel(const FastParams 
     twi[k1] = t.y;
   }
   const int L = p.L, S = p.S;
+  const bool use_power = p.use_power != 0;
 
   for (int item = blockIdx.x; item < p.n_items; item += gridDim.x) {
     const int b = item / p.tiles_per_utt;
@@ -107,42 +126,68 @@ __global__ __launch_bounds__(WAVES * 64) void stft_fast_kernel(const FastParams 
 #pragma unroll 1
     for (int it = 0; it < G::ITERS; ++it) {
       const int fr = (g % G::GPH) * N2 + (g / G::GPH) * 32 + wave * G::ITERS + it;
-      const int64_t t = t0 + fr;
-      const bool valid = t < nfr;
+      const bool valid = t0 + fr < nfr;
+      if (!__any(valid)) continue;  // uniform: all of this wave's frames lie past the end
+      // lanes of a frame past the end recompute the last frame; their rows are never stored
+      const int64_t t = valid ? t0 + fr : nfr - 1;
       const int start = (int)(t * S) - p.pad_left;
-      // 0: every sample inside the signal, 1: one bounce suffices, 2: general reflection
+      // 0: every row read lies inside the signal, 1: one bounce suffices, 2: general reflection
       int mode = 0;
-      if (valid) {
-        if (start < 0 || start + L > n) mode = 1;
-        if (start < -n || start + L > 2 * n) mode = 2;
-      }
+      if (start < 0 || start + NROWS * N2 > n) mode = 1;
+      if (start < -n || start + L > 2 * n) mode = 2;
       const int wmode = __builtin_amdgcn_readfirstlane(
           __any(mode == 2) ? 2 : (__any(mode == 1) ? 1 : 0));
 
       float a[N1];
       float energy = 0.0f;
+      if (wmode == 0) {
+        // interior frames: one 64-bit lane pointer + immediate offsets, no index math, no
+        // predicates.  Lanes past the frame's end in the last row read samples that belong to
+        // the next frame; the window (exactly 0 there, applied with the 0 * x = 0 multiply
+        // below) removes them.
+        const float *xp = x + (start + r);
 #pragma unroll
-      for (int n1 = 0; n1 < N1; ++n1) {
-        a[n1] = 0.0f;
-        if (n1 * N2 < L) {  // uniform
+        for (int n1 = 0; n1 < NROWS; ++n1) a[n1] = xp[n1 * N2];
+      } else {
+        // a frame of this wave touches a signal end: gather through LDS with a rolled loop
+        float *tmp = reinterpret_cast<float *>(stage) + wave * (G::EXCH_F2_PER_WAVE * 2);
+#pragma unroll 1
+        for (int n1 = 0; n1 < NROWS; ++n1) {
           const int idx = n1 * N2 + r;
-          if (valid && idx < L) {
+          float v = 0.0f;
+          if (idx < L) {
             int i = start + idx;
             if (wmode == 1) {
               i = i < 0 ? -1 - i : (i >= n ? 2 * n - 1 - i : i);
-            } else if (wmode == 2) {
+            } else {
               i = (int)reflect_index((int64_t)i, (int64_t)n);
             }
-            a[n1] = x[i];
+            v = x[i];
           }
+          tmp[n1 * 64 + lane] = v;
         }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+        for (int n1 = 0; n1 < NROWS; ++n1) a[n1] = tmp[n1 * 64 + lane];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
       }
       if (p.include_energy) {
 #pragma unroll
-        for (int n1 = 0; n1 < N1; ++n1) energy = fmaf(a[n1], a[n1], energy);
+        for (int n1 = 0; n1 < NROWS; ++n1) {
+          const float v = (n1 * N2 + r < L) ? a[n1] : 0.0f;
+          energy = fmaf(v, v, energy);
+        }
       }
+      // v_mul_legacy_f32: 0 * anything = 0, so samples under a zero of the window (the
+      // padding lanes above included) never leak a NaN/Inf into the frame
 #pragma unroll
-      for (int n1 = 0; n1 < N1; ++n1) a[n1] *= win[n1];
+      for (int n1 = 0; n1 < NROWS; ++n1) a[n1] = mul_legacy(a[n1], win[n1]);
+#pragma unroll
+      for (int n1 = NROWS; n1 < N1; ++n1) a[n1] = 0.0f;
 
       float even_sum, odd_sum, Ar[H1], Ai[H1];
       inl::rdft_scaled<N1>(a, even_sum, odd_sum, Ar, Ai);
@@ -181,20 +226,29 @@ __global__ __launch_bounds__(WAVES * 64) void stft_fast_kernel(const FastParams 
         inl::CFFT<N2, 1>::run(zr, zi, Yr, Yi);
         if (q == 0 && r == 0) {
           // bins that are multiples of N1/2: real DFT of the 2*N2 even/odd sums
+          float pw[N2 + 1];
           inl::rdft_finish_power<2 * N2>(Yr, Yi, [&](auto mm, float re, float im) {
-            constexpr int m = decltype(mm)::value;
-            float pw = re * re + im * im;
-            if (!p.use_power) pw = sqrtf(pw);
-            Pf[(m * H1) * FS] = pw;
+            pw[decltype(mm)::value] = re * re + im * im;
           });
+          if (!use_power) {
+#pragma unroll
+            for (int m = 0; m <= N2; ++m) pw[m] = __builtin_amdgcn_sqrtf(pw[m]);
+          }
+#pragma unroll
+          for (int m = 0; m <= N2; ++m) Pf[(m * H1) * FS] = pw[m];
         } else {
+          float pw[N2];
+#pragma unroll
+          for (int k2 = 0; k2 < N2; ++k2) pw[k2] = Yr[k2] * Yr[k2] + Yi[k2] * Yi[k2];
+          if (!use_power) {
+#pragma unroll
+            for (int k2 = 0; k2 < N2; ++k2) pw[k2] = __builtin_amdgcn_sqrtf(pw[k2]);
+          }
 #pragma unroll
           for (int k2 = 0; k2 < N2; ++k2) {
-            float pw = Yr[k2] * Yr[k2] + Yi[k2] * Yi[k2];
-            if (!p.use_power) pw = sqrtf(pw);
             // bin kk + N1*k2, or its mirror image when beyond N/2
             const int bin = (k2 < N2 / 2) ? kk + N1 * k2 : N - kk - N1 * k2;
-            Pf[bin * FS] = pw;
+            Pf[bin * FS] = pw[k2];
           }
         }
       }
@@ -224,7 +278,7 @@ __global__ __launch_bounds__(WAVES * 64) void stft_fast_kernel(const FastParams 
     }
     if (p.include_energy && wave == WAVES - 1) {
       float e = Pl[NB * FS] * p.inv_L;
-      if (!p.use_power) e = sqrtf(e);
+      if (!use_power) e = __builtin_amdgcn_sqrtf(e);
       if (p.use_log) e = __logf(fmaxf(e, p.log_floor));
       stage[lane * CP] = e;
     }
@@ -247,9 +301,242 @@ __global__ __launch_bounds__(WAVES * 64) void stft_fast_kernel(const FastParams 
   }
 }
 
+// ====================================================================================
+// Variant 2: every wavefront works alone (no workgroup barrier, no batch buffer).
+//
+// A wave takes 64/N2 consecutive frames of one utterance, runs the same two-step FFT as
+// above, leaves |X|^2 of its frames in its own LDS area (P[frame][bin], aliased over the
+// exchange area) and integrates the filters itself: lane (frame g, j) owns every N2-th filter
+// of the length-sorted filter list ("ELL" layout: slot s of lane j is filter order[s*N2+j];
+// all lanes walk slot s for the same number of steps, shorter rows padded with zero weights).
+// 9 KB of LDS per wave and <= 168 VGPRs give 12 resident waves per CU instead of 8, and no
+// wave ever waits for another.
+// ====================================================================================
+template <int N1, int N2, int WAVES, int NROWS>
+struct WaveGeom {
+  static constexpr int N = N1 * N2;
+  static constexpr int H1 = N1 / 2;
+  static constexpr int CPL = H1 / N2;
+  static constexpr int GROUPS = 64 / N2;
+  static constexpr int NB = N / 2 + 1;
+  static constexpr int RS = N2 + 2;
+  static constexpr int EXCH_F2 = GROUPS * H1 * RS;  // float2 per wave
+  // P row stride: >= NB + 1 (energy) and = 16 (mod 32) so that the two frames sharing a
+  // 32-lane half write to disjoint banks
+  static constexpr int PSTR = ((NB + 1 + 15) / 32) * 32 + 16;
+  static_assert(GROUPS * PSTR <= EXCH_F2 * 2, "P must fit over the exchange area");
+  static_assert(EXCH_F2 * 2 >= 64 * NROWS, "edge-frame gather reuses the exchange area");
+  static_assert(H1 % N2 == 0 && CPL >= 1 && N2 <= 32 && (RS * 8) % 16 == 0, "geometry");
+};
+
+template <int N1, int N2, int WAVES, int NROWS>
+__global__ __launch_bounds__(WAVES * 64, 3) void stft_wave_kernel(const FastParams p) {
+  using G = WaveGeom<N1, N2, WAVES, NROWS>;
+  constexpr int N = G::N, H1 = G::H1, RS = G::RS, NB = G::NB, PSTR = G::PSTR;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int g = lane / N2, r = lane % N2;
+  float *wbase = smem + wave * (G::EXCH_F2 * 2);
+  float2 *exch = reinterpret_cast<float2 *>(wbase) + g * H1 * RS;
+  float *Pg = wbase + g * PSTR;
+  // filter table -> LDS once per workgroup (read by every wave, every iteration)
+  float2 *ell = reinterpret_cast<float2 *>(smem + WAVES * (G::EXCH_F2 * 2));
+  for (int i = threadIdx.x; i < p.ell_steps * N2; i += WAVES * 64) ell[i] = p.ell[i];
+  __syncthreads();
+
+  float win[NROWS];
+  float twr[H1], twi[H1];
+#pragma unroll
+  for (int n1 = 0; n1 < NROWS; ++n1) win[n1] = p.win_lane[r * N1 + n1];
+#pragma unroll
+  for (int k1 = 1; k1 < H1; ++k1) {
+    const float2 t = p.tw_lane[r * H1 + k1];
+    twr[k1] = t.x;
+    twi[k1] = t.y;
+  }
+  const int L = p.L, S = p.S;
+  const bool use_power = p.use_power != 0;
+  const int col0 = p.include_energy ? 1 : 0;
+
+  // work items: (utterance, chunk of GROUPS consecutive frames); the waves of a workgroup
+  // take neighbouring chunks so that overlapping samples are shared through the CU's L1
+  const int stride = gridDim.x * WAVES;
+  int b = 0;
+  int chunk = blockIdx.x * WAVES + wave;
+  while (chunk >= p.chunks_per_utt) {
+    chunk -= p.chunks_per_utt;
+    ++b;
+  }
+  for (; b < p.num_utts; chunk += stride) {
+    while (chunk >= p.chunks_per_utt) {
+      chunk -= p.chunks_per_utt;
+      ++b;
+    }
+    if (b >= p.num_utts) break;
+    const int64_t nfr = p.nframes[b];
+    const int64_t tb = (int64_t)chunk * G::GROUPS;
+    if (tb >= nfr) continue;  // uniform
+    const int n = (int)p.lengths[b];
+    const float *x = p.sig + p.offsets[b];
+    const bool valid = tb + g < nfr;
+    const int64_t t = valid ? tb + g : nfr - 1;
+    const int start = (int)(t * S) - p.pad_left;
+    int mode = 0;
+    if (start < 0 || start + NROWS * N2 > n) mode = 1;
+    if (start < -n || start + L > 2 * n) mode = 2;
+    const int wmode = __builtin_amdgcn_readfirstlane(
+        __any(mode == 2) ? 2 : (__any(mode == 1) ? 1 : 0));
+
+    float a[N1];
+    float energy = 0.0f;
+    if (wmode == 0) {
+      const float *xp = x + (start + r);
+#pragma unroll
+      for (int n1 = 0; n1 < NROWS; ++n1) a[n1] = xp[n1 * N2];
+    } else {
+      float *tmp = wbase;
+#pragma unroll 1
+      for (int n1 = 0; n1 < NROWS; ++n1) {
+        const int idx = n1 * N2 + r;
+        float v = 0.0f;
+        if (idx < L) {
+          int i = start + idx;
+          if (wmode == 1) {
+            i = i < 0 ? -1 - i : (i >= n ? 2 * n - 1 - i : i);
+          } else {
+            i = (int)reflect_index((int64_t)i, (int64_t)n);
+          }
+          v = x[i];
+        }
+        tmp[n1 * 64 + lane] = v;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+      for (int n1 = 0; n1 < NROWS; ++n1) a[n1] = tmp[n1 * 64 + lane];
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+    if (p.include_energy) {
+#pragma unroll
+      for (int n1 = 0; n1 < NROWS; ++n1) {
+        const float v = (n1 * N2 + r < L) ? a[n1] : 0.0f;
+        energy = fmaf(v, v, energy);
+      }
+    }
+#pragma unroll
+    for (int n1 = 0; n1 < NROWS; ++n1) a[n1] = mul_legacy(a[n1], win[n1]);
+#pragma unroll
+    for (int n1 = NROWS; n1 < N1; ++n1) a[n1] = 0.0f;
+
+    float even_sum, odd_sum, Ar[H1], Ai[H1];
+    inl::rdft_scaled<N1>(a, even_sum, odd_sum, Ar, Ai);
+    {
+      float *row0 = reinterpret_cast<float *>(exch);
+      row0[r] = even_sum;
+      row0[N2 + r] = odd_sum;
+    }
+#pragma unroll
+    for (int k1 = 1; k1 < H1; ++k1) {
+      float2 v;
+      v.x = Ar[k1] * twr[k1] - Ai[k1] * twi[k1];
+      v.y = Ar[k1] * twi[k1] + Ai[k1] * twr[k1];
+      exch[k1 * RS + r] = v;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+    float pw[G::CPL][N2 + 1];
+#pragma unroll
+    for (int q = 0; q < G::CPL; ++q) {
+      const int kk = q * N2 + r;
+      const float4 *row = reinterpret_cast<const float4 *>(exch + kk * RS);
+      float zr[N2], zi[N2], Yr[N2], Yi[N2];
+#pragma unroll
+      for (int j = 0; j < N2 / 2; ++j) {
+        const float4 v = row[j];
+        zr[2 * j] = v.x;
+        zi[2 * j] = v.y;
+        zr[2 * j + 1] = v.z;
+        zi[2 * j + 1] = v.w;
+      }
+      inl::CFFT<N2, 1>::run(zr, zi, Yr, Yi);
+      if (q == 0 && r == 0) {
+        inl::rdft_finish_power<2 * N2>(Yr, Yi, [&](auto mm, float re, float im) {
+          pw[q][decltype(mm)::value] = re * re + im * im;
+        });
+      } else {
+#pragma unroll
+        for (int k2 = 0; k2 < N2; ++k2) pw[q][k2] = Yr[k2] * Yr[k2] + Yi[k2] * Yi[k2];
+        pw[q][N2] = 0.0f;
+      }
+      if (!use_power) {
+#pragma unroll
+        for (int k2 = 0; k2 <= N2; ++k2) pw[q][k2] = __builtin_amdgcn_sqrtf(pw[q][k2]);
+      }
+    }
+    // every lane has finished reading the exchange area (same wave, in order): reuse it as P
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+    for (int q = 0; q < G::CPL; ++q) {
+      const int kk = q * N2 + r;
+      if (q == 0 && r == 0) {
+#pragma unroll
+        for (int m = 0; m <= N2; ++m) Pg[m * H1] = pw[q][m];
+      } else {
+#pragma unroll
+        for (int k2 = 0; k2 < N2; ++k2) {
+          const int bin = (k2 < N2 / 2) ? kk + N1 * k2 : N - kk - N1 * k2;
+          Pg[bin] = pw[q][k2];
+        }
+      }
+    }
+    if (p.include_energy) {
+#pragma unroll
+      for (int off = N2 / 2; off >= 1; off >>= 1) energy += __shfl_xor(energy, off, 64);
+      if (r == 0) Pg[NB] = energy;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+    // ---- filter bank: lane (g, r) walks its filters of every slot
+    float *orow = p.out + (p.row_off[b] + t) * p.out_stride;
+    const char *Pbytes = reinterpret_cast<const char *>(Pg);
+    int step = 0;
+    for (int sl = 0; sl < p.ell_slots; ++sl) {
+      const int end = p.ell_end[sl];
+      float acc = 0.0f;
+      for (; step < end; ++step) {
+        const float2 e = ell[step * N2 + r];
+        const float pv = *reinterpret_cast<const float *>(Pbytes + __float_as_int(e.x));
+        acc = fmaf(e.y, pv, acc);
+      }
+      if (p.use_log) acc = __logf(fmaxf(acc, p.log_floor));
+      const int f = p.ell_filt[sl * N2 + r];
+      if (valid && f >= 0) orow[col0 + f] = acc;
+    }
+    if (p.include_energy && r == 0) {
+      float e = Pg[NB] * p.inv_L;
+      if (!use_power) e = __builtin_amdgcn_sqrtf(e);
+      if (p.use_log) e = __logf(fmaxf(e, p.log_floor));
+      if (valid) orow[0] = e;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  }
+}
+
 // ----------------------------------------------------------------------- host side ---
 
-template <int N1, int N2, int WAVES>
+template <int N1, int N2, int WAVES, int NROWS>
 static int32_t launch_geom(const pds_stft_plan *plan, const BatchArgs &a) {
   using G = FastGeom<N1, N2, WAVES>;
   const FastTables &ft = plan->fast;
@@ -283,7 +570,7 @@ static int32_t launch_geom(const pds_stft_plan *plan, const BatchArgs &a) {
     return PDS_ERR_INVALID;
   }
   p.n_items = (int)items;
-  auto kern = stft_fast_kernel<N1, N2, WAVES>;
+  auto kern = stft_fast_kernel<N1, N2, WAVES, NROWS>;
   static bool attr_set = false;  // per instantiation
   if (!attr_set) {
     PDS_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -297,13 +584,89 @@ static int32_t launch_geom(const pds_stft_plan *plan, const BatchArgs &a) {
   return PDS_OK;
 }
 
+static void fill_common(FastParams &p, const pds_stft_plan *plan, const BatchArgs &a) {
+  const FastTables &ft = plan->fast;
+  p.sig = (const float *)a.d_signal;
+  p.offsets = a.d_offsets;
+  p.lengths = a.d_lengths;
+  p.nframes = a.d_nframes;
+  p.row_off = a.d_row_off;
+  p.out = (float *)a.d_out;
+  p.out_stride = a.out_stride;
+  p.win_lane = ft.d_window;
+  p.tw_lane = (const float2 *)ft.d_twiddle;
+  p.f_rowptr = plan->d_row_ptr;
+  p.f_order = ft.d_order;
+  p.t_off = ft.d_toff;
+  p.t_w = ft.d_wval;
+  p.L = plan->d.frame_length;
+  p.S = plan->d.frame_shift;
+  p.pad_left = a.pad_left;
+  p.F = plan->d.num_filts;
+  p.include_energy = plan->d.include_energy;
+  p.use_power = plan->d.use_power;
+  p.use_log = plan->d.use_log;
+  p.log_floor = (float)plan->d.log_floor;
+  p.inv_L = 1.0f / (float)plan->d.frame_length;
+  p.tiles_per_utt = 0;
+  p.n_items = 0;
+  p.ell = (const float2 *)ft.d_ell;
+  p.ell_filt = ft.d_ell_filt;
+  p.ell_end = ft.d_ell_end;
+  p.ell_steps = ft.ell_steps;
+  p.ell_slots = ft.ell_slots;
+  p.chunks_per_utt = 0;
+  p.num_utts = a.B;
+}
+
+template <int N1, int N2, int WAVES, int NROWS>
+static int32_t launch_wave(const pds_stft_plan *plan, const BatchArgs &a) {
+  using G = WaveGeom<N1, N2, WAVES, NROWS>;
+  const FastTables &ft = plan->fast;
+  FastParams p;
+  fill_common(p, plan, a);
+  const int64_t chunks = (a.max_frames + G::GROUPS - 1) / G::GROUPS;
+  if (chunks * a.B > 0x7fffffff || chunks > 0x3fffffff) {
+    set_error("stft_batch: too many frame chunks in one call");
+    return PDS_ERR_INVALID;
+  }
+  p.chunks_per_utt = (int)chunks;
+  const size_t smem = (size_t)WAVES * G::EXCH_F2 * 8 + (size_t)ft.ell_steps * N2 * 8;
+  auto kern = stft_wave_kernel<N1, N2, WAVES, NROWS>;
+  static size_t attr_smem = 0;  // per instantiation
+  if (smem > attr_smem) {
+    PDS_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)smem));
+    attr_smem = smem;
+  }
+  int wgs_per_cu = (int)((160 * 1024) / smem);
+  if (wgs_per_cu > 12 / WAVES) wgs_per_cu = 12 / WAVES;  // launch_bounds: 3 waves per SIMD
+  if (wgs_per_cu < 1) wgs_per_cu = 1;
+  int64_t grid = (int64_t)ft.num_cus * wgs_per_cu;
+  const int64_t need = (chunks * a.B + WAVES - 1) / WAVES;
+  if (grid > need) grid = need;
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(WAVES * 64), smem, a.stream, p);
+  PDS_HIP(hipGetLastError());
+  return PDS_OK;
+}
+
 int32_t launch_stft_fast_f32(const pds_stft_plan *plan, const BatchArgs &a) {
   // frame starts and reflected indices are formed in 32-bit arithmetic
-  switch (plan->fast.kind) {
-    case 512: return launch_geom<32, 16, 8>(plan, a);
-    case 256: return launch_geom<32, 8, 8>(plan, a);
-    default: break;
+  // instantiated row counts: the common frame lengths exactly (25 ms @ 16 kHz = 25 rows of 16,
+  // 20 ms = 20, 30 ms = 30, ...); other lengths use the next larger one
+#define PDS_ROWS_CASE(N1, N2, R)                                          \
+  if (rows <= R)                                                          \
+    return plan->fast.variant == 1 ? launch_geom<N1, N2, 8, R>(plan, a)   \
+                                   : launch_wave<N1, N2, 4, R>(plan, a);
+  const int rows = plan->fast.rows;
+  if (plan->fast.kind == 512) {
+    PDS_ROWS_CASE(32, 16, 20) PDS_ROWS_CASE(32, 16, 25) PDS_ROWS_CASE(32, 16, 28)
+    PDS_ROWS_CASE(32, 16, 30) PDS_ROWS_CASE(32, 16, 32)
+  } else if (plan->fast.kind == 256) {
+    PDS_ROWS_CASE(32, 8, 20) PDS_ROWS_CASE(32, 8, 25) PDS_ROWS_CASE(32, 8, 28)
+    PDS_ROWS_CASE(32, 8, 30) PDS_ROWS_CASE(32, 8, 32)
   }
+#undef PDS_ROWS_CASE
   set_error("stft_batch: no fused kernel for this plan");
   return PDS_ERR_INVALID;
 }
@@ -346,7 +709,45 @@ int32_t fast_tables_create(pds_stft_plan *plan, const double *window, const int3
     toff[q] = col[q] * FS;
     wv[q] = (float)val[q];
   }
+  // ELL form of the filter table for the wave-independent kernel: slot s of lane j is
+  // filter order[s * n2 + j]; every lane walks slot s for as many steps as its longest row
+  const int slots = (d.num_filts + n2 - 1) / n2;
+  std::vector<int32_t> ell_filt((size_t)slots * n2, -1), ell_end(slots, 0);
+  std::vector<float> ell;  // (offset bits, weight) pairs
+  int steps = 0;
+  for (int sl = 0; sl < slots; ++sl) {
+    int longest = 0;
+    for (int j = 0; j < n2 && sl * n2 + j < d.num_filts; ++j) {
+      const int f = order[sl * n2 + j];
+      ell_filt[(size_t)sl * n2 + j] = f;
+      longest = std::max(longest, row_ptr[f + 1] - row_ptr[f]);
+    }
+    for (int t = 0; t < longest; ++t)
+      for (int j = 0; j < n2; ++j) {
+        const int f = ell_filt[(size_t)sl * n2 + j];
+        int32_t off = 0;
+        float w = 0.0f;
+        if (f >= 0 && row_ptr[f] + t < row_ptr[f + 1]) {
+          off = col[row_ptr[f] + t] * 4;
+          w = (float)val[row_ptr[f] + t];
+        }
+        float offbits;
+        std::memcpy(&offbits, &off, 4);
+        ell.push_back(offbits);
+        ell.push_back(w);
+      }
+    steps += longest;
+    ell_end[sl] = steps;
+  }
+  ft.ell_steps = steps;
+  ft.ell_slots = slots;
+  const char *variant = std::getenv("PDS_STFT_VARIANT");
+  ft.variant = (variant && variant[0] == '1') ? 1 : 2;
+  if ((size_t)steps * n2 * 8 > 64 * 1024) ft.variant = 1;  // table too large for LDS
   int32_t rc = PDS_OK;
+  if (rc == PDS_OK) rc = upload(&ft.d_ell, ell.data(), ell.size());
+  if (rc == PDS_OK) rc = upload(&ft.d_ell_filt, ell_filt.data(), ell_filt.size());
+  if (rc == PDS_OK) rc = upload(&ft.d_ell_end, ell_end.data(), ell_end.size());
   if (rc == PDS_OK) rc = upload(&ft.d_window, win.data(), win.size());
   if (rc == PDS_OK) rc = upload(&ft.d_twiddle, tw.data(), tw.size());
   if (rc == PDS_OK) rc = upload(&ft.d_order, order.data(), order.size());
@@ -358,6 +759,7 @@ int32_t fast_tables_create(pds_stft_plan *plan, const double *window, const int3
   ft.num_cus = prop.multiProcessorCount;
   ft.n1 = n1;
   ft.n2 = n2;
+  ft.rows = (d.frame_length + n2 - 1) / n2;
   ft.kind = d.dft_size;
   return PDS_OK;
 }
@@ -369,6 +771,9 @@ void fast_tables_destroy(pds_stft_plan *plan) {
   (void)hipFree(ft.d_order);
   (void)hipFree(ft.d_toff);
   (void)hipFree(ft.d_wval);
+  (void)hipFree(ft.d_ell);
+  (void)hipFree(ft.d_ell_filt);
+  (void)hipFree(ft.d_ell_end);
   ft = FastTables();
 }
 
