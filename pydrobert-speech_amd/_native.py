@@ -9,7 +9,8 @@ import os
 from ctypes import POINTER, Structure, c_char_p, c_double, c_int32, c_int64, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libpds_amd.so")
+# PDS_AMD_LIB selects another build of the same library (kernel tuning experiments)
+LIB_PATH = os.environ.get("PDS_AMD_LIB") or os.path.join(_HERE, "csrc", "libpds_amd.so")
 
 PDS_OK = 0
 

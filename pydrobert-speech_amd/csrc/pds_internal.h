@@ -31,6 +31,7 @@ struct FastTables {
   float *d_wval = nullptr;    // [nnz] weights
   int variant = 2;            // 1: batch kernel (workgroup barriers), 2: wave-independent
   float *d_ell = nullptr;     // [ell_steps][n2] (LDS byte offset bits, weight)
+  float *d_tw_special = nullptr;  // [n2] (re, im) of e^{-2 pi i r / (2 n2)}
   int32_t *d_ell_filt = nullptr;  // [ell_slots][n2]
   int32_t *d_ell_end = nullptr;   // [ell_slots]
   int ell_steps = 0, ell_slots = 0;

@@ -52,6 +52,7 @@ struct FastParams {
   const float2 *ell;       // [ell_steps][N2] (LDS byte offset of the bin as int bits, weight)
   const int32_t *ell_filt; // [ell_slots][N2] filter handled by lane j in slot s, or -1
   const int32_t *ell_end;  // [ell_slots] end step of each slot (cumulative)
+  const float2 *tw_special; // [N2] e^{-2 pi i r / (2 N2)}
   int ell_steps, ell_slots;
   int chunks_per_utt, num_utts;
 };
@@ -329,8 +330,16 @@ struct WaveGeom {
   static_assert(H1 % N2 == 0 && CPL >= 1 && N2 <= 32 && (RS * 8) % 16 == 0, "geometry");
 };
 
+// tuning knobs (workgroup size in waves, resident waves per SIMD the register budget is for)
+#ifndef PDS_WAVE_WAVES
+#define PDS_WAVE_WAVES 8
+#endif
+#ifndef PDS_WAVE_MINW
+#define PDS_WAVE_MINW 4
+#endif
+
 template <int N1, int N2, int WAVES, int NROWS>
-__global__ __launch_bounds__(WAVES * 64, 3) void stft_wave_kernel(const FastParams p) {
+__global__ __launch_bounds__(WAVES * 64, PDS_WAVE_MINW) void stft_wave_kernel(const FastParams p) {
   using G = WaveGeom<N1, N2, WAVES, NROWS>;
   constexpr int N = G::N, H1 = G::H1, RS = G::RS, NB = G::NB, PSTR = G::PSTR;
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -355,6 +364,9 @@ __global__ __launch_bounds__(WAVES * 64, 3) void stft_wave_kernel(const FastPara
     twr[k1] = t.x;
     twi[k1] = t.y;
   }
+  // W_(2 N2)^r for the distributed untangling of the even/odd-sum column
+  const float2 sw = p.tw_special[r];
+  const float swr = sw.x, swi = sw.y;
   const int L = p.L, S = p.S;
   const bool use_power = p.use_power != 0;
   const int col0 = p.include_energy ? 1 : 0;
@@ -450,7 +462,7 @@ __global__ __launch_bounds__(WAVES * 64, 3) void stft_wave_kernel(const FastPara
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
-    float pw[G::CPL][N2 + 1];
+    float pw[G::CPL][N2];
 #pragma unroll
     for (int q = 0; q < G::CPL; ++q) {
       const int kk = q * N2 + r;
@@ -465,37 +477,67 @@ __global__ __launch_bounds__(WAVES * 64, 3) void stft_wave_kernel(const FastPara
         zi[2 * j + 1] = v.w;
       }
       inl::CFFT<N2, 1>::run(zr, zi, Yr, Yi);
-      if (q == 0 && r == 0) {
-        inl::rdft_finish_power<2 * N2>(Yr, Yi, [&](auto mm, float re, float im) {
-          pw[q][decltype(mm)::value] = re * re + im * im;
-        });
-      } else {
 #pragma unroll
-        for (int k2 = 0; k2 < N2; ++k2) pw[q][k2] = Yr[k2] * Yr[k2] + Yi[k2] * Yi[k2];
-        pw[q][N2] = 0.0f;
-      }
-      if (!use_power) {
+      for (int k2 = 0; k2 < N2; ++k2) pw[q][k2] = Yr[k2] * Yr[k2] + Yi[k2] * Yi[k2];
+      if (q == 0) {
+        // lane 0 transformed the packed even/odd sums: Y = FFT(c[2m] + i c[2m+1]).  The
+        // real-DFT untangling of its N2/2 + 1 bin pairs is spread over lanes 0..N2/2 of the
+        // group: lane 0 parks Y in its (now consumed) exchange row, every lane picks a pair.
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (r == 0) {
+          float4 *dst = reinterpret_cast<float4 *>(exch);
 #pragma unroll
-        for (int k2 = 0; k2 <= N2; ++k2) pw[q][k2] = __builtin_amdgcn_sqrtf(pw[q][k2]);
+          for (int j = 0; j < N2 / 2; ++j)
+            dst[j] = make_float4(Yr[2 * j], Yi[2 * j], Yr[2 * j + 1], Yi[2 * j + 1]);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
       }
     }
-    // every lane has finished reading the exchange area (same wave, in order): reuse it as P
+    // bins m * N1/2 and (N2 - m) * N1/2 from Y[m] and Y[N2 - m] (Y[N2] = Y[0]); m = r
+    float sp0 = 0.0f, sp1 = 0.0f;
+    const int sm = r <= N2 / 2 ? r : 0;
+    {
+      const float2 ya = exch[sm];
+      const float2 yb = exch[(N2 - sm) % N2];
+      const float sr = ya.x + yb.x, si = ya.y - yb.y;
+      const float dr = ya.x - yb.x, di = ya.y + yb.y;
+      const float tr = swr * di + swi * dr;
+      const float ti = swi * di - swr * dr;
+      const float ar = sr + tr, ai = si + ti;  // 2 X[m]
+      const float br = sr - tr, bi = ti - si;  // 2 X[N2 - m]
+      sp0 = 0.25f * (ar * ar + ai * ai);
+      sp1 = 0.25f * (br * br + bi * bi);
+    }
+    if (!use_power) {
+#pragma unroll
+      for (int q = 0; q < G::CPL; ++q)
+#pragma unroll
+        for (int k2 = 0; k2 < N2; ++k2) pw[q][k2] = __builtin_amdgcn_sqrtf(pw[q][k2]);
+      sp0 = __builtin_amdgcn_sqrtf(sp0);
+      sp1 = __builtin_amdgcn_sqrtf(sp1);
+    }
+    // every lane is done with the exchange area (same wave, in order): reuse it as P
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #pragma unroll
     for (int q = 0; q < G::CPL; ++q) {
       const int kk = q * N2 + r;
-      if (q == 0 && r == 0) {
-#pragma unroll
-        for (int m = 0; m <= N2; ++m) Pg[m * H1] = pw[q][m];
-      } else {
+      if (!(q == 0 && r == 0)) {
 #pragma unroll
         for (int k2 = 0; k2 < N2; ++k2) {
           const int bin = (k2 < N2 / 2) ? kk + N1 * k2 : N - kk - N1 * k2;
           Pg[bin] = pw[q][k2];
         }
       }
+    }
+    if (r <= N2 / 2) {
+      Pg[sm * H1] = sp0;
+      Pg[(N2 - sm) * H1] = sp1;
     }
     if (p.include_energy) {
 #pragma unroll
@@ -506,18 +548,29 @@ __global__ __launch_bounds__(WAVES * 64, 3) void stft_wave_kernel(const FastPara
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
-    // ---- filter bank: lane (g, r) walks its filters of every slot
+    // ---- filter bank: lane (g, r) walks its filters of every slot; slot lengths are padded
+    // to multiples of 8 so that eight table reads, then eight P reads, are in flight at once
     float *orow = p.out + (p.row_off[b] + t) * p.out_stride;
     const char *Pbytes = reinterpret_cast<const char *>(Pg);
     int step = 0;
     for (int sl = 0; sl < p.ell_slots; ++sl) {
       const int end = p.ell_end[sl];
-      float acc = 0.0f;
-      for (; step < end; ++step) {
-        const float2 e = ell[step * N2 + r];
-        const float pv = *reinterpret_cast<const float *>(Pbytes + __float_as_int(e.x));
-        acc = fmaf(e.y, pv, acc);
+      float acc0 = 0.0f, acc1 = 0.0f;
+      for (; step < end; step += 8) {
+        float2 e[8];
+        float pv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) e[u] = ell[(step + u) * N2 + r];
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+          pv[u] = *reinterpret_cast<const float *>(Pbytes + __float_as_int(e[u].x));
+#pragma unroll
+        for (int u = 0; u < 8; u += 2) {
+          acc0 = fmaf(e[u].y, pv[u], acc0);
+          acc1 = fmaf(e[u + 1].y, pv[u + 1], acc1);
+        }
       }
+      float acc = acc0 + acc1;
       if (p.use_log) acc = __logf(fmaxf(acc, p.log_floor));
       const int f = p.ell_filt[sl * N2 + r];
       if (valid && f >= 0) orow[col0 + f] = acc;
@@ -613,6 +666,7 @@ static void fill_common(FastParams &p, const pds_stft_plan *plan, const BatchArg
   p.ell = (const float2 *)ft.d_ell;
   p.ell_filt = ft.d_ell_filt;
   p.ell_end = ft.d_ell_end;
+  p.tw_special = (const float2 *)ft.d_tw_special;
   p.ell_steps = ft.ell_steps;
   p.ell_slots = ft.ell_slots;
   p.chunks_per_utt = 0;
@@ -640,7 +694,7 @@ static int32_t launch_wave(const pds_stft_plan *plan, const BatchArgs &a) {
     attr_smem = smem;
   }
   int wgs_per_cu = (int)((160 * 1024) / smem);
-  if (wgs_per_cu > 12 / WAVES) wgs_per_cu = 12 / WAVES;  // launch_bounds: 3 waves per SIMD
+  if (wgs_per_cu > 4 * PDS_WAVE_MINW / WAVES) wgs_per_cu = 4 * PDS_WAVE_MINW / WAVES;
   if (wgs_per_cu < 1) wgs_per_cu = 1;
   int64_t grid = (int64_t)ft.num_cus * wgs_per_cu;
   const int64_t need = (chunks * a.B + WAVES - 1) / WAVES;
@@ -657,7 +711,7 @@ int32_t launch_stft_fast_f32(const pds_stft_plan *plan, const BatchArgs &a) {
 #define PDS_ROWS_CASE(N1, N2, R)                                          \
   if (rows <= R)                                                          \
     return plan->fast.variant == 1 ? launch_geom<N1, N2, 8, R>(plan, a)   \
-                                   : launch_wave<N1, N2, 4, R>(plan, a);
+                                   : launch_wave<N1, N2, PDS_WAVE_WAVES, R>(plan, a);
   const int rows = plan->fast.rows;
   if (plan->fast.kind == 512) {
     PDS_ROWS_CASE(32, 16, 20) PDS_ROWS_CASE(32, 16, 25) PDS_ROWS_CASE(32, 16, 28)
@@ -722,6 +776,7 @@ int32_t fast_tables_create(pds_stft_plan *plan, const double *window, const int3
       ell_filt[(size_t)sl * n2 + j] = f;
       longest = std::max(longest, row_ptr[f + 1] - row_ptr[f]);
     }
+    longest = (longest + 7) / 8 * 8;  // the kernel walks a slot eight steps at a time
     for (int t = 0; t < longest; ++t)
       for (int j = 0; j < n2; ++j) {
         const int f = ell_filt[(size_t)sl * n2 + j];
@@ -745,6 +800,13 @@ int32_t fast_tables_create(pds_stft_plan *plan, const double *window, const int3
   ft.variant = (variant && variant[0] == '1') ? 1 : 2;
   if ((size_t)steps * n2 * 8 > 64 * 1024) ft.variant = 1;  // table too large for LDS
   int32_t rc = PDS_OK;
+  std::vector<float> tws((size_t)n2 * 2);
+  for (int r = 0; r < n2; ++r) {
+    const double ang = -2.0 * M_PI * (double)r / (double)(2 * n2);
+    tws[2 * r] = (float)std::cos(ang);
+    tws[2 * r + 1] = (float)std::sin(ang);
+  }
+  if (rc == PDS_OK) rc = upload(&ft.d_tw_special, tws.data(), tws.size());
   if (rc == PDS_OK) rc = upload(&ft.d_ell, ell.data(), ell.size());
   if (rc == PDS_OK) rc = upload(&ft.d_ell_filt, ell_filt.data(), ell_filt.size());
   if (rc == PDS_OK) rc = upload(&ft.d_ell_end, ell_end.data(), ell_end.size());
@@ -772,6 +834,7 @@ void fast_tables_destroy(pds_stft_plan *plan) {
   (void)hipFree(ft.d_toff);
   (void)hipFree(ft.d_wval);
   (void)hipFree(ft.d_ell);
+  (void)hipFree(ft.d_tw_special);
   (void)hipFree(ft.d_ell_filt);
   (void)hipFree(ft.d_ell_end);
   ft = FastTables();
