@@ -30,11 +30,11 @@ struct FastTables {
   int32_t *d_toff = nullptr;  // [nnz] LDS offset (bin * row stride) of each table entry
   float *d_wval = nullptr;    // [nnz] weights
   int variant = 2;            // 1: batch kernel (workgroup barriers), 2: wave-independent
-  float *d_ell = nullptr;     // [ell_steps][n2] (LDS byte offset bits, weight)
-  float *d_tw_special = nullptr;  // [n2] (re, im) of e^{-2 pi i r / (2 n2)}
-  int32_t *d_ell_filt = nullptr;  // [ell_slots][n2]
-  int32_t *d_ell_end = nullptr;   // [ell_slots]
-  int ell_steps = 0, ell_slots = 0;
+  float *d_ell_w = nullptr;       // ELL weight rows (see stft_fast.hip)
+  int32_t *d_ell_meta = nullptr;  // [ell_slots][n2] first bin | (filter + 1) << 16
+  int32_t *d_ell_len = nullptr;   // [ell_slots]
+  int32_t *d_ell_woff = nullptr;  // [ell_slots]
+  int ell_wfloats = 0, ell_slots = 0;
 };
 
 }  // namespace pds

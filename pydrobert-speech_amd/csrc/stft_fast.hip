@@ -49,11 +49,11 @@ struct FastParams {
   float log_floor, inv_L;
   int tiles_per_utt, n_items;
   // wave-independent variant (stft_wave_kernel): filter table in ELL form, see below
-  const float2 *ell;       // [ell_steps][N2] (LDS byte offset of the bin as int bits, weight)
-  const int32_t *ell_filt; // [ell_slots][N2] filter handled by lane j in slot s, or -1
-  const int32_t *ell_end;  // [ell_slots] end step of each slot (cumulative)
-  const float2 *tw_special; // [N2] e^{-2 pi i r / (2 N2)}
-  int ell_steps, ell_slots;
+  const float *ell_w;      // per slot: [N2][len + 4] dense weight rows (row r = lane r's filter)
+  const int32_t *ell_meta; // [ell_slots][N2] first bin of the row | (filter + 1) << 16
+  const int32_t *ell_len;  // [ell_slots] row length in bins (multiple of 8)
+  const int32_t *ell_woff; // [ell_slots] start of the slot's rows inside ell_w (floats)
+  int ell_wfloats, ell_slots;
   int chunks_per_utt, num_utts;
 };
 
@@ -349,9 +349,14 @@ __global__ __launch_bounds__(WAVES * 64, PDS_WAVE_MINW) void stft_wave_kernel(co
   float *wbase = smem + wave * (G::EXCH_F2 * 2);
   float2 *exch = reinterpret_cast<float2 *>(wbase) + g * H1 * RS;
   float *Pg = wbase + g * PSTR;
-  // filter table -> LDS once per workgroup (read by every wave, every iteration)
-  float2 *ell = reinterpret_cast<float2 *>(smem + WAVES * (G::EXCH_F2 * 2));
-  for (int i = threadIdx.x; i < p.ell_steps * N2; i += WAVES * 64) ell[i] = p.ell[i];
+  // filter table -> LDS once per workgroup (read by every wave, every iteration): per-slot
+  // weight rows, then per (slot, lane) the row's first bin and filter index
+  float *ellw = smem + WAVES * (G::EXCH_F2 * 2);
+  int *ell_meta = reinterpret_cast<int *>(ellw + p.ell_wfloats);
+  for (int i = threadIdx.x; i < p.ell_wfloats; i += WAVES * 64) ellw[i] = p.ell_w[i];
+  for (int i = threadIdx.x; i < p.ell_slots * N2; i += WAVES * 64) ell_meta[i] = p.ell_meta[i];
+  // the wave areas start out zeroed so that never-written P padding is finite
+  for (int i = threadIdx.x; i < WAVES * G::EXCH_F2 * 2; i += WAVES * 64) smem[i] = 0.0f;
   __syncthreads();
 
   float win[NROWS];
@@ -364,9 +369,6 @@ __global__ __launch_bounds__(WAVES * 64, PDS_WAVE_MINW) void stft_wave_kernel(co
     twr[k1] = t.x;
     twi[k1] = t.y;
   }
-  // W_(2 N2)^r for the distributed untangling of the even/odd-sum column
-  const float2 sw = p.tw_special[r];
-  const float swr = sw.x, swi = sw.y;
   const int L = p.L, S = p.S;
   const bool use_power = p.use_power != 0;
   const int col0 = p.include_energy ? 1 : 0;
@@ -462,7 +464,7 @@ __global__ __launch_bounds__(WAVES * 64, PDS_WAVE_MINW) void stft_wave_kernel(co
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
-    float pw[G::CPL][N2];
+    float pw[G::CPL][N2 + 1];
 #pragma unroll
     for (int q = 0; q < G::CPL; ++q) {
       const int kk = q * N2 + r;
@@ -477,48 +479,24 @@ __global__ __launch_bounds__(WAVES * 64, PDS_WAVE_MINW) void stft_wave_kernel(co
         zi[2 * j + 1] = v.w;
       }
       inl::CFFT<N2, 1>::run(zr, zi, Yr, Yi);
+      if (q == 0 && r == 0) {
+        // lane 0 transformed the packed even/odd sums: untangle to the bins m * N1/2.
+        // (Spreading this over the idle lanes through LDS or DPP was measured/estimated to
+        // cost more LDS time than the ~100 VALU issue slots it saves.)
+        inl::rdft_finish_power<2 * N2>(Yr, Yi, [&](auto mm, float re, float im) {
+          pw[q][decltype(mm)::value] = re * re + im * im;
+        });
+      } else {
 #pragma unroll
-      for (int k2 = 0; k2 < N2; ++k2) pw[q][k2] = Yr[k2] * Yr[k2] + Yi[k2] * Yi[k2];
-      if (q == 0) {
-        // lane 0 transformed the packed even/odd sums: Y = FFT(c[2m] + i c[2m+1]).  The
-        // real-DFT untangling of its N2/2 + 1 bin pairs is spread over lanes 0..N2/2 of the
-        // group: lane 0 parks Y in its (now consumed) exchange row, every lane picks a pair.
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        if (r == 0) {
-          float4 *dst = reinterpret_cast<float4 *>(exch);
-#pragma unroll
-          for (int j = 0; j < N2 / 2; ++j)
-            dst[j] = make_float4(Yr[2 * j], Yi[2 * j], Yr[2 * j + 1], Yi[2 * j + 1]);
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        for (int k2 = 0; k2 < N2; ++k2) pw[q][k2] = Yr[k2] * Yr[k2] + Yi[k2] * Yi[k2];
+        pw[q][N2] = 0.0f;
       }
-    }
-    // bins m * N1/2 and (N2 - m) * N1/2 from Y[m] and Y[N2 - m] (Y[N2] = Y[0]); m = r
-    float sp0 = 0.0f, sp1 = 0.0f;
-    const int sm = r <= N2 / 2 ? r : 0;
-    {
-      const float2 ya = exch[sm];
-      const float2 yb = exch[(N2 - sm) % N2];
-      const float sr = ya.x + yb.x, si = ya.y - yb.y;
-      const float dr = ya.x - yb.x, di = ya.y + yb.y;
-      const float tr = swr * di + swi * dr;
-      const float ti = swi * di - swr * dr;
-      const float ar = sr + tr, ai = si + ti;  // 2 X[m]
-      const float br = sr - tr, bi = ti - si;  // 2 X[N2 - m]
-      sp0 = 0.25f * (ar * ar + ai * ai);
-      sp1 = 0.25f * (br * br + bi * bi);
     }
     if (!use_power) {
 #pragma unroll
       for (int q = 0; q < G::CPL; ++q)
 #pragma unroll
-        for (int k2 = 0; k2 < N2; ++k2) pw[q][k2] = __builtin_amdgcn_sqrtf(pw[q][k2]);
-      sp0 = __builtin_amdgcn_sqrtf(sp0);
-      sp1 = __builtin_amdgcn_sqrtf(sp1);
+        for (int k2 = 0; k2 <= N2; ++k2) pw[q][k2] = __builtin_amdgcn_sqrtf(pw[q][k2]);
     }
     // every lane is done with the exchange area (same wave, in order): reuse it as P
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -527,7 +505,10 @@ __global__ __launch_bounds__(WAVES * 64, PDS_WAVE_MINW) void stft_wave_kernel(co
 #pragma unroll
     for (int q = 0; q < G::CPL; ++q) {
       const int kk = q * N2 + r;
-      if (!(q == 0 && r == 0)) {
+      if (q == 0 && r == 0) {
+#pragma unroll
+        for (int m = 0; m <= N2; ++m) Pg[m * H1] = pw[q][m];
+      } else {
 #pragma unroll
         for (int k2 = 0; k2 < N2; ++k2) {
           const int bin = (k2 < N2 / 2) ? kk + N1 * k2 : N - kk - N1 * k2;
@@ -535,44 +516,44 @@ __global__ __launch_bounds__(WAVES * 64, PDS_WAVE_MINW) void stft_wave_kernel(co
         }
       }
     }
-    if (r <= N2 / 2) {
-      Pg[sm * H1] = sp0;
-      Pg[(N2 - sm) * H1] = sp1;
-    }
+    // slots past the last bin are read (with weight 0) by the filter walk: keep them finite
+    if (r < G::PSTR - NB - 1) Pg[NB + 1 + r] = 0.0f;
     if (p.include_energy) {
 #pragma unroll
       for (int off = N2 / 2; off >= 1; off >>= 1) energy += __shfl_xor(energy, off, 64);
       if (r == 0) Pg[NB] = energy;
+    } else if (r == 0) {
+      Pg[NB] = 0.0f;
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
-    // ---- filter bank: lane (g, r) walks its filters of every slot; slot lengths are padded
-    // to multiples of 8 so that eight table reads, then eight P reads, are in flight at once
+    // ---- filter bank: lane (g, r) integrates one filter per slot.  Rows are dense bin ranges
+    // starting on a multiple of 4 bins, so weights and powers both arrive as 16-byte reads
     float *orow = p.out + (p.row_off[b] + t) * p.out_stride;
-    const char *Pbytes = reinterpret_cast<const char *>(Pg);
-    int step = 0;
     for (int sl = 0; sl < p.ell_slots; ++sl) {
-      const int end = p.ell_end[sl];
-      float acc0 = 0.0f, acc1 = 0.0f;
-      for (; step < end; step += 8) {
-        float2 e[8];
-        float pv[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) e[u] = ell[(step + u) * N2 + r];
-#pragma unroll
-        for (int u = 0; u < 8; ++u)
-          pv[u] = *reinterpret_cast<const float *>(Pbytes + __float_as_int(e[u].x));
-#pragma unroll
-        for (int u = 0; u < 8; u += 2) {
-          acc0 = fmaf(e[u].y, pv[u], acc0);
-          acc1 = fmaf(e[u + 1].y, pv[u + 1], acc1);
-        }
+      const int len = p.ell_len[sl];                 // steps of this slot, multiple of 8
+      const int wstride = len + 4;                   // floats; conflict-free row skew
+      const float4 *wrow = reinterpret_cast<const float4 *>(ellw + p.ell_woff[sl] + r * wstride);
+      const int meta = ell_meta[sl * N2 + r];        // first bin (multiple of 4) | filter << 16
+      const float4 *prow = reinterpret_cast<const float4 *>(Pg + (meta & 0xffff));
+      float acc0 = 0.0f, acc1 = 0.0f, acc2 = 0.0f, acc3 = 0.0f;
+      for (int t4 = 0; t4 < len / 4; t4 += 2) {
+        const float4 w0 = wrow[t4], w1 = wrow[t4 + 1];
+        const float4 p0 = prow[t4], p1 = prow[t4 + 1];
+        acc0 = fmaf(w0.x, p0.x, acc0);
+        acc1 = fmaf(w0.y, p0.y, acc1);
+        acc2 = fmaf(w0.z, p0.z, acc2);
+        acc3 = fmaf(w0.w, p0.w, acc3);
+        acc0 = fmaf(w1.x, p1.x, acc0);
+        acc1 = fmaf(w1.y, p1.y, acc1);
+        acc2 = fmaf(w1.z, p1.z, acc2);
+        acc3 = fmaf(w1.w, p1.w, acc3);
       }
-      float acc = acc0 + acc1;
+      float acc = (acc0 + acc1) + (acc2 + acc3);
       if (p.use_log) acc = __logf(fmaxf(acc, p.log_floor));
-      const int f = p.ell_filt[sl * N2 + r];
+      const int f = (meta >> 16) - 1;
       if (valid && f >= 0) orow[col0 + f] = acc;
     }
     if (p.include_energy && r == 0) {
@@ -663,11 +644,11 @@ static void fill_common(FastParams &p, const pds_stft_plan *plan, const BatchArg
   p.inv_L = 1.0f / (float)plan->d.frame_length;
   p.tiles_per_utt = 0;
   p.n_items = 0;
-  p.ell = (const float2 *)ft.d_ell;
-  p.ell_filt = ft.d_ell_filt;
-  p.ell_end = ft.d_ell_end;
-  p.tw_special = (const float2 *)ft.d_tw_special;
-  p.ell_steps = ft.ell_steps;
+  p.ell_w = ft.d_ell_w;
+  p.ell_meta = ft.d_ell_meta;
+  p.ell_len = ft.d_ell_len;
+  p.ell_woff = ft.d_ell_woff;
+  p.ell_wfloats = ft.ell_wfloats;
   p.ell_slots = ft.ell_slots;
   p.chunks_per_utt = 0;
   p.num_utts = a.B;
@@ -685,7 +666,8 @@ static int32_t launch_wave(const pds_stft_plan *plan, const BatchArgs &a) {
     return PDS_ERR_INVALID;
   }
   p.chunks_per_utt = (int)chunks;
-  const size_t smem = (size_t)WAVES * G::EXCH_F2 * 8 + (size_t)ft.ell_steps * N2 * 8;
+  const size_t smem = (size_t)WAVES * G::EXCH_F2 * 8 + (size_t)ft.ell_wfloats * 4 +
+                      (size_t)ft.ell_slots * N2 * 4;
   auto kern = stft_wave_kernel<N1, N2, WAVES, NROWS>;
   static size_t attr_smem = 0;  // per instantiation
   if (smem > attr_smem) {
@@ -763,53 +745,56 @@ int32_t fast_tables_create(pds_stft_plan *plan, const double *window, const int3
     toff[q] = col[q] * FS;
     wv[q] = (float)val[q];
   }
-  // ELL form of the filter table for the wave-independent kernel: slot s of lane j is
-  // filter order[s * n2 + j]; every lane walks slot s for as many steps as its longest row
+  // ELL form of the filter table for the wave-independent kernel: slot s of lane j is filter
+  // order[s * n2 + j].  A row is the filter's dense bin range, extended down to a multiple of
+  // 4 bins and up to the slot's common length (a multiple of 8); zero weights fill the rest.
   const int slots = (d.num_filts + n2 - 1) / n2;
-  std::vector<int32_t> ell_filt((size_t)slots * n2, -1), ell_end(slots, 0);
-  std::vector<float> ell;  // (offset bits, weight) pairs
-  int steps = 0;
+  const int pstr = ((N / 2 + 2 + 15) / 32) * 32 + 16;  // WaveGeom::PSTR
+  std::vector<int32_t> ell_meta((size_t)slots * n2, 0), ell_len(slots, 0), ell_woff(slots, 0);
+  std::vector<float> ell_w;
+  bool ell_ok = true;
   for (int sl = 0; sl < slots; ++sl) {
-    int longest = 0;
+    int longest = 8;
+    std::vector<int> first(n2, 0);
     for (int j = 0; j < n2 && sl * n2 + j < d.num_filts; ++j) {
       const int f = order[sl * n2 + j];
-      ell_filt[(size_t)sl * n2 + j] = f;
-      longest = std::max(longest, row_ptr[f + 1] - row_ptr[f]);
+      if (row_ptr[f + 1] == row_ptr[f]) continue;
+      const int c0 = col[row_ptr[f]] & ~3, c1 = col[row_ptr[f + 1] - 1];  // cols ascend
+      first[j] = c0;
+      longest = std::max(longest, (c1 - c0 + 1 + 7) / 8 * 8);
     }
-    longest = (longest + 7) / 8 * 8;  // the kernel walks a slot eight steps at a time
-    for (int t = 0; t < longest; ++t)
-      for (int j = 0; j < n2; ++j) {
-        const int f = ell_filt[(size_t)sl * n2 + j];
-        int32_t off = 0;
-        float w = 0.0f;
-        if (f >= 0 && row_ptr[f] + t < row_ptr[f + 1]) {
-          off = col[row_ptr[f] + t] * 4;
-          w = (float)val[row_ptr[f] + t];
-        }
-        float offbits;
-        std::memcpy(&offbits, &off, 4);
-        ell.push_back(offbits);
-        ell.push_back(w);
+    ell_len[sl] = longest;
+    ell_woff[sl] = (int32_t)ell_w.size();
+    const int wstride = longest + 4;
+    ell_w.resize(ell_w.size() + (size_t)n2 * wstride, 0.0f);
+    for (int j = 0; j < n2; ++j) {
+      int f = -1;
+      if (sl * n2 + j < d.num_filts) f = order[sl * n2 + j];
+      if (first[j] + longest > pstr) {
+        // keep every 16-byte read inside the frame's P row
+        const int shift = (first[j] + longest - pstr + 3) / 4 * 4;
+        first[j] -= shift;
+        if (first[j] < 0) ell_ok = false;
       }
-    steps += longest;
-    ell_end[sl] = steps;
+      ell_meta[(size_t)sl * n2 + j] = first[j] | ((f + 1) << 16);
+      if (f < 0) continue;
+      for (int q = row_ptr[f]; q < row_ptr[f + 1]; ++q) {
+        const int t = col[q] - first[j];
+        if (t < 0 || t >= longest) { ell_ok = false; continue; }
+        ell_w[(size_t)ell_woff[sl] + (size_t)j * wstride + t] = (float)val[q];
+      }
+    }
   }
-  ft.ell_steps = steps;
+  ft.ell_wfloats = (int)ell_w.size();
   ft.ell_slots = slots;
   const char *variant = std::getenv("PDS_STFT_VARIANT");
   ft.variant = (variant && variant[0] == '1') ? 1 : 2;
-  if ((size_t)steps * n2 * 8 > 64 * 1024) ft.variant = 1;  // table too large for LDS
+  if (!ell_ok || d.num_filts > 32767 || ell_w.size() * 4 > 48 * 1024) ft.variant = 1;
   int32_t rc = PDS_OK;
-  std::vector<float> tws((size_t)n2 * 2);
-  for (int r = 0; r < n2; ++r) {
-    const double ang = -2.0 * M_PI * (double)r / (double)(2 * n2);
-    tws[2 * r] = (float)std::cos(ang);
-    tws[2 * r + 1] = (float)std::sin(ang);
-  }
-  if (rc == PDS_OK) rc = upload(&ft.d_tw_special, tws.data(), tws.size());
-  if (rc == PDS_OK) rc = upload(&ft.d_ell, ell.data(), ell.size());
-  if (rc == PDS_OK) rc = upload(&ft.d_ell_filt, ell_filt.data(), ell_filt.size());
-  if (rc == PDS_OK) rc = upload(&ft.d_ell_end, ell_end.data(), ell_end.size());
+  if (rc == PDS_OK) rc = upload(&ft.d_ell_w, ell_w.data(), ell_w.size());
+  if (rc == PDS_OK) rc = upload(&ft.d_ell_meta, ell_meta.data(), ell_meta.size());
+  if (rc == PDS_OK) rc = upload(&ft.d_ell_len, ell_len.data(), ell_len.size());
+  if (rc == PDS_OK) rc = upload(&ft.d_ell_woff, ell_woff.data(), ell_woff.size());
   if (rc == PDS_OK) rc = upload(&ft.d_window, win.data(), win.size());
   if (rc == PDS_OK) rc = upload(&ft.d_twiddle, tw.data(), tw.size());
   if (rc == PDS_OK) rc = upload(&ft.d_order, order.data(), order.size());
@@ -833,10 +818,10 @@ void fast_tables_destroy(pds_stft_plan *plan) {
   (void)hipFree(ft.d_order);
   (void)hipFree(ft.d_toff);
   (void)hipFree(ft.d_wval);
-  (void)hipFree(ft.d_ell);
-  (void)hipFree(ft.d_tw_special);
-  (void)hipFree(ft.d_ell_filt);
-  (void)hipFree(ft.d_ell_end);
+  (void)hipFree(ft.d_ell_w);
+  (void)hipFree(ft.d_ell_meta);
+  (void)hipFree(ft.d_ell_len);
+  (void)hipFree(ft.d_ell_woff);
   ft = FastTables();
 }
 
