@@ -23,13 +23,9 @@ struct FastTables {
   int kind = 0;               // 0 = not available for this plan, else the DFT size served
   int n1 = 0, n2 = 0;         // N = n1 * n2: in-lane real DFT size x lanes per frame
   int rows = 0;               // ceil(frame_length / n2): rows of n2 samples per frame
-  int num_cus = 0;            // persistent grid size
+  int num_cus = 0;            // sizes the persistent grid
   float *d_window = nullptr;  // [n2][n1] window in lane order, zero padded
   float *d_twiddle = nullptr; // [n2][n1/2] (re, im) inter-stage twiddles in lane order
-  int32_t *d_order = nullptr; // [F] filters sorted by row length (longest first)
-  int32_t *d_toff = nullptr;  // [nnz] LDS offset (bin * row stride) of each table entry
-  float *d_wval = nullptr;    // [nnz] weights
-  int variant = 2;            // 1: batch kernel (workgroup barriers), 2: wave-independent
   float *d_ell_w = nullptr;       // ELL weight rows (see stft_fast.hip)
   int32_t *d_ell_meta = nullptr;  // [ell_slots][n2] first bin | (filter + 1) << 16
   int32_t *d_ell_len = nullptr;   // [ell_slots]

@@ -83,14 +83,14 @@ __global__ __launch_bounds__(64 * FPB) void stft_generic_kernel(
   if (include_energy) {
     e = wave_sum(e) / (T)L;
     if (!use_power) e = sqrt(e);
-    if (use_log) e = log(e > log_floor ? e : log_floor);
+    if (use_log) e = log(log_floor > e ? log_floor : e);  // Python max(): NaN stays NaN
     if (lane == 0) orow[0] = e;
     orow += 1;
   }
   for (int f = lane; f < F; f += 64) {
     T acc = 0;
     for (int q = row_ptr[f]; q < row_ptr[f + 1]; ++q) acc += val[q] * pw[col[q]];
-    if (use_log) acc = log(acc > log_floor ? acc : log_floor);
+    if (use_log) acc = log(log_floor > acc ? log_floor : acc);
     orow[f] = acc;
   }
 }

@@ -177,3 +177,70 @@ def test_full_size_linearity_property(computers):
     # frames are independent of batch position: utterance 3 alone gives the same rows
     y3, _ = comp.compute_packed(x[3 * n : 4 * n].clone(), [0], [n])
     assert torch.equal(y3, y1[3000:4000])
+
+
+def _params_from_computer(comp):
+    return orc.StftParams(
+        frame_length=comp.frame_length, frame_shift=comp.frame_shift, dft_size=comp.dft_size,
+        window=np.asarray(comp._window), starts=list(comp._filt_start_idxs),
+        taps=[np.asarray(t) for t in comp._truncated_filts], is_real=comp.bank.is_real,
+        centered=comp.frame_style == "centered", kaldi_shift=comp.kaldi_shift,
+        include_energy=comp.includes_energy, use_power=bool(comp._power), use_log=bool(comp._log),
+    )
+
+
+EXTRA_GEOMETRIES = {
+    # N = 2048 (64 x 32 lanes): 25 ms at 48 kHz
+    "n2048_fbank_48k": {"name": "stft", "bank": {"name": "fbank", "num_filts": 60, "sampling_rate": 48000},
+                        "frame_length_ms": 25, "use_power": True, "include_energy": True},
+    # N = 2048, magnitude spectrum, complex bank, causal frames
+    "n2048_gammatone_44k": {"name": "stft", "bank": {"name": "gammatone", "scaling_function": "bark",
+                            "num_filts": 30, "sampling_rate": 44100}, "frame_length_ms": 30, "use_power": False},
+    # N = 1024 with every row in use (L = 1024)
+    "n1024_full_rows": {"name": "stft", "bank": {"name": "tri", "scaling_function": "mel", "num_filts": 50,
+                        "sampling_rate": 32000}, "frame_length_ms": 32, "frame_shift_ms": 8, "use_power": True},
+    # N = 128 (16 x 8 lanes): 12.5 ms at 8 kHz
+    "n128_fbank_8k": {"name": "stft", "bank": {"name": "fbank", "num_filts": 12, "sampling_rate": 8000},
+                      "frame_length_ms": 12.5, "frame_shift_ms": 5, "use_power": True, "kaldi_shift": True},
+    # N = 512 with a frame length that is not a multiple of the 16-sample row (L = 330)
+    "n512_partial_row": {"name": "stft", "bank": {"name": "gabor", "scaling_function": "mel", "num_filts": 33},
+                         "frame_length_ms": 20.625, "use_power": True, "include_energy": True},
+    # N = 256 with L = 200 (25 rows of 8)
+    "n256_tri_8k": {"name": "stft", "bank": {"name": "tri", "scaling_function": "linear", "num_filts": 17,
+                    "sampling_rate": 8000, "scaling_function": {"name": "linear", "low_hz": 0.0}},
+                    "frame_length_ms": 25, "use_log": False},
+}
+
+
+@pytest.mark.parametrize("name", sorted(EXTRA_GEOMETRIES))
+def test_other_kernel_geometries_match_oracle(name):
+    # configurations without reference fixtures: the fused kernel (and the generic one) against
+    # the pinned oracle driven by OUR tables (which test_host.py pins for the fixture configs)
+    import torch
+
+    comp = build(EXTRA_GEOMETRIES[name])
+    assert comp.kernel_kind == comp.dft_size, (comp.kernel_kind, comp.dft_size)
+    p = _params_from_computer(comp)
+    L, S = comp.frame_length, comp.frame_shift
+    rng = np.random.default_rng(99)
+    lens = [0, L // 2, L // 2 + 1, L + 3, 37 * S + 11, 5 * L, 3]
+    sigs = [(3000 * rng.standard_normal(n)).astype("f4") for n in lens]
+    got = comp.compute_full_batch(sigs)
+    for x, y in zip(sigs, got):
+        assert_features_close(y, orc.compute_full(x, p), what=(name, len(x)), **F32)
+    x = torch.from_numpy(sigs[4]).cuda()
+    y_gen, _ = comp.compute_packed(x, [0], [len(sigs[4])], generic=True)
+    assert_features_close(y_gen.cpu().numpy(), got[4], what=(name, "generic"), **F32)
+
+
+def test_nonfinite_samples_do_not_leak_into_other_frames(computers):
+    # a NaN poisons exactly the frames that contain it (like the reference), no neighbours
+    comp = computers["c2_tri_mel40"]
+    x = (3000 * np.random.default_rng(1).standard_normal(16000)).astype("f4")
+    x[8000] = np.nan
+    y = comp.compute_full(x)
+    L, S, pad = comp.frame_length, comp.frame_shift, comp.pad_left
+    t = np.arange(y.shape[0])
+    contains = (t * S - pad <= 8000) & (8000 < t * S - pad + L)
+    assert np.isnan(y[contains]).all()
+    assert np.isfinite(y[~contains]).all()
