@@ -45,11 +45,12 @@ struct FastParams {
   int64_t out_stride;
   const float *win_lane;    // [N2][N1]   window[N2*n1 + n2], zero beyond L
   const float2 *tw_lane;    // [N2][N1/2] W_N^(n2*k1), pre-scaled (see rdft_scaled)
+  const float2 *tw_special; // [N2] e^{-2 pi i r / (2 N2)}
   const float *ell_w;       // per slot: [N2][len + 4] dense weight rows (row j = lane j's filter)
   const int32_t *ell_meta;  // [slots][N2] first bin of the row | (filter + 1) << 16
   const int32_t *ell_len;   // [slots] row length in bins (multiple of 8)
   const int32_t *ell_woff;  // [slots] start of the slot's rows inside ell_w (floats)
-  int ell_wfloats, ell_slots, ell_in_lds, ell_meta_pad;  // meta_pad: ints, multiple of 4
+  int ell_wfloats, ell_slots, ell_meta_pad;  // meta_pad: ints, multiple of 4
   int L, S, pad_left, include_energy, use_power, use_log;
   float log_floor, inv_L;
   int chunks_per_utt, num_utts;
@@ -60,6 +61,14 @@ __device__ __forceinline__ float mul_legacy(float x, float y) {
   float z;
   asm("v_mul_legacy_f32 %0, %1, %2" : "=v"(z) : "v"(x), "v"(y));
   return z;
+}
+
+// DPP row_shr:M of `src` into `old`: lane i of a 16-lane row takes src of lane i - M; lanes whose
+// source would lie outside the row keep `old`
+template <int M>
+__device__ __forceinline__ float dpp_row_shr_keep(float old, float src) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(src),
+                                                    0x110 + M, 0xf, 0xf, false));
 }
 
 __device__ __forceinline__ void wave_sync() {
@@ -90,7 +99,8 @@ struct WaveGeom {
   static_assert(NROWS <= N1 && NROWS > 0, "rows");
 };
 
-template <int N1, int N2, int NROWS, int WAVES, int MINW>
+// ELL_LDS: the filter weight rows are staged in LDS (else read from global memory through L1/L2)
+template <int N1, int N2, int NROWS, int WAVES, int MINW, bool ELL_LDS>
 __global__ __launch_bounds__(WAVES * 64, MINW) void stft_wave_kernel(const FastParams p) {
   using G = WaveGeom<N1, N2, NROWS>;
   constexpr int N = G::N, H1 = G::H1, RS = G::RS, NB = G::NB, PSTR = G::PSTR;
@@ -107,7 +117,7 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void stft_wave_kernel(const FastP
   int *meta_lds = reinterpret_cast<int *>(smem + WAVES * (G::EXCH_F2 * 2));
   float *ellw_lds = reinterpret_cast<float *>(meta_lds + p.ell_meta_pad);
   for (int i = threadIdx.x; i < p.ell_slots * N2; i += WAVES * 64) meta_lds[i] = p.ell_meta[i];
-  if (p.ell_in_lds)
+  if constexpr (ELL_LDS)
     for (int i = threadIdx.x; i < p.ell_wfloats; i += WAVES * 64) ellw_lds[i] = p.ell_w[i];
   // the wave areas start out zeroed so that never-written P padding is finite
   for (int i = threadIdx.x; i < WAVES * G::EXCH_F2 * 2; i += WAVES * 64) smem[i] = 0.0f;
@@ -127,6 +137,9 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void stft_wave_kernel(const FastP
   const int L = p.L, S = p.S;
   const bool use_power = p.use_power != 0;
   const int col0 = p.include_energy ? 1 : 0;
+  const int gS = g * S;
+  // W_(2 N2)^r: twiddle of lane r in the distributed untangling of the even/odd-sum column
+  const float2 sw = p.tw_special[r];
 
   // work items: (utterance, chunk of GROUPS consecutive frames); the waves of a workgroup
   // take neighbouring chunks so that overlapping samples are shared through the CU's L1
@@ -143,16 +156,25 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void stft_wave_kernel(const FastP
     if (tb >= nfr) continue;  // uniform
     const int n = (int)p.lengths[b];
     const float *x = p.sig + p.offsets[b];
-    // lanes of a frame past the end recompute the last frame; their rows are never stored
-    const bool valid = tb + g < nfr;
-    const int64_t t = valid ? tb + g : nfr - 1;
-    const int start = (int)(t * S) - p.pad_left;
-    // 0: every row read lies inside the signal, 1: one bounce suffices, 2: general reflection
-    int mode = 0;
-    if (start < 0 || start + NROWS * N2 > n) mode = 1;
-    if (start < -n || start + L > 2 * n) mode = 2;
-    const int wmode = __builtin_amdgcn_readfirstlane(
-        __any(mode == 2) ? 2 : (__any(mode == 1) ? 1 : 0));
+    // Common case, decided on scalars: all GROUPS frames exist and every row they read lies
+    // inside the signal.  Otherwise per-lane bookkeeping: lanes of a frame past the end
+    // recompute the last frame (their rows are never stored); frames touching a signal end are
+    // gathered with reflected indices (1: one bounce suffices, 2: general reflection).
+    const int start0 = (int)(tb * S) - p.pad_left;
+    bool valid = true;
+    int64_t t = tb + g;
+    int start = start0 + gS;
+    int wmode = 0;
+    if (!(tb + G::GROUPS <= nfr && start0 >= 0 &&
+          start0 + (G::GROUPS - 1) * S + NROWS * N2 <= n)) {
+      valid = tb + g < nfr;
+      t = valid ? tb + g : nfr - 1;
+      start = (int)(t * S) - p.pad_left;
+      int mode = 0;
+      if (start < 0 || start + NROWS * N2 > n) mode = 1;
+      if (start < -n || start + L > 2 * n) mode = 2;
+      wmode = __builtin_amdgcn_readfirstlane(__any(mode == 2) ? 2 : (__any(mode == 1) ? 1 : 0));
+    }
 
     float a[N1];
     float energy = 0.0f;
@@ -217,6 +239,7 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void stft_wave_kernel(const FastP
     wave_sync();
 
     float pw[G::CPL][N2 + 1];
+    float sp0 = 0.0f, sp1 = 0.0f;  // N2 == 16: the two special bins of lane r <= N2/2
 #pragma unroll
     for (int q = 0; q < G::CPL; ++q) {
       const int kk = q * N2 + r;
@@ -231,10 +254,36 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void stft_wave_kernel(const FastP
         zi[2 * j + 1] = v.w;
       }
       inl::CFFT<N2, 1>::run(zr, zi, Yr, Yi);
-      if (q == 0 && r == 0) {
-        // lane 0 transformed the packed sums c[2m] + i c[2m+1]: untangle to the bins m * N1/2.
-        // (Spreading this over the idle lanes through LDS cost more LDS time than the ~100
-        // VALU issue slots it saves: 2.03 -> 2.20 G frames/s going back to in-lane.)
+      if constexpr (N2 == 16) {
+        // regular columns; lane 0 (q = 0) holds Y = FFT(c[2m] + i c[2m+1]) of the even/odd sums
+#pragma unroll
+        for (int k2 = 0; k2 < N2; ++k2) pw[q][k2] = Yr[k2] * Yr[k2] + Yi[k2] * Yi[k2];
+        pw[q][N2] = 0.0f;
+        if (q == 0) {
+          // The bins m * N1/2 need Y[m] and Y[N2 - m]: a lane group is one DPP row, so
+          // "row_shr:m, keep old where the source lane is outside the row", applied for
+          // m = 1, 2, ... in order, leaves lane m with lane 0's register m.  Lanes 0..N2/2 then
+          // untangle one bin pair each -- 32 moves + 20 flops for every lane instead of a
+          // ~130-instruction block that only lane 0 needs.
+          float ar = Yr[0], ai = Yi[0], br = Yr[0], bi = Yi[0];
+          inl::static_for<1, N2 / 2 + 1>([&](auto mm) {
+            constexpr int m = decltype(mm)::value;
+            ar = dpp_row_shr_keep<m>(ar, Yr[m]);
+            ai = dpp_row_shr_keep<m>(ai, Yi[m]);
+            br = dpp_row_shr_keep<m>(br, Yr[N2 - m]);
+            bi = dpp_row_shr_keep<m>(bi, Yi[N2 - m]);
+          });
+          const float sr = ar + br, si = ai - bi;
+          const float dr = ar - br, di = ai + bi;
+          const float tr = sw.x * di + sw.y * dr;
+          const float ti = sw.y * di - sw.x * dr;
+          const float xr = sr + tr, xi = si + ti;  // 2 X[m]
+          const float yr = sr - tr, yi = ti - si;  // 2 X[N2 - m]
+          sp0 = 0.25f * (xr * xr + xi * xi);
+          sp1 = 0.25f * (yr * yr + yi * yi);
+        }
+      } else if (q == 0 && r == 0) {
+        // other lane-group sizes: lane 0 untangles its packed-sum transform itself
         inl::rdft_finish_power<2 * N2>(Yr, Yi, [&](auto mm, float re, float im) {
           pw[q][decltype(mm)::value] = re * re + im * im;
         });
@@ -249,6 +298,8 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void stft_wave_kernel(const FastP
       for (int q = 0; q < G::CPL; ++q)
 #pragma unroll
         for (int k2 = 0; k2 <= N2; ++k2) pw[q][k2] = __builtin_amdgcn_sqrtf(pw[q][k2]);
+      sp0 = __builtin_amdgcn_sqrtf(sp0);
+      sp1 = __builtin_amdgcn_sqrtf(sp1);
     }
     // every lane is done with the exchange area (same wave, in order): reuse it as P
     wave_sync();
@@ -256,8 +307,10 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void stft_wave_kernel(const FastP
     for (int q = 0; q < G::CPL; ++q) {
       const int kk = q * N2 + r;
       if (q == 0 && r == 0) {
+        if constexpr (N2 != 16) {
 #pragma unroll
-        for (int m = 0; m <= N2; ++m) Pg[m * H1] = pw[q][m];
+          for (int m = 0; m <= N2; ++m) Pg[m * H1] = pw[q][m];
+        }
       } else {
 #pragma unroll
         for (int k2 = 0; k2 < N2; ++k2) {
@@ -265,6 +318,12 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void stft_wave_kernel(const FastP
           const int bin = (k2 < N2 / 2) ? kk + N1 * k2 : N - kk - N1 * k2;
           Pg[bin] = pw[q][k2];
         }
+      }
+    }
+    if constexpr (N2 == 16) {
+      if (r <= N2 / 2) {
+        Pg[r * H1] = sp0;
+        Pg[(N2 - r) * H1] = sp1;
       }
     }
     // slots past the last bin are read (with weight 0) by the filter walk: keep them finite
@@ -286,34 +345,18 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void stft_wave_kernel(const FastP
       const float4 *prow = reinterpret_cast<const float4 *>(Pg + (meta & 0xffff));
       const int woff = p.ell_woff[sl] + r * (len + 4);  // + 4: conflict-free row skew
       float acc0 = 0.0f, acc1 = 0.0f, acc2 = 0.0f, acc3 = 0.0f;
-      if (p.ell_in_lds) {
-        const float4 *wrow = reinterpret_cast<const float4 *>(ellw_lds + woff);
-        for (int t4 = 0; t4 < len / 4; t4 += 2) {
-          const float4 w0 = wrow[t4], w1 = wrow[t4 + 1];
-          const float4 p0 = prow[t4], p1 = prow[t4 + 1];
-          acc0 = fmaf(w0.x, p0.x, acc0);
-          acc1 = fmaf(w0.y, p0.y, acc1);
-          acc2 = fmaf(w0.z, p0.z, acc2);
-          acc3 = fmaf(w0.w, p0.w, acc3);
-          acc0 = fmaf(w1.x, p1.x, acc0);
-          acc1 = fmaf(w1.y, p1.y, acc1);
-          acc2 = fmaf(w1.z, p1.z, acc2);
-          acc3 = fmaf(w1.w, p1.w, acc3);
-        }
-      } else {
-        const float4 *wrow = reinterpret_cast<const float4 *>(p.ell_w + woff);
-        for (int t4 = 0; t4 < len / 4; t4 += 2) {
-          const float4 w0 = wrow[t4], w1 = wrow[t4 + 1];
-          const float4 p0 = prow[t4], p1 = prow[t4 + 1];
-          acc0 = fmaf(w0.x, p0.x, acc0);
-          acc1 = fmaf(w0.y, p0.y, acc1);
-          acc2 = fmaf(w0.z, p0.z, acc2);
-          acc3 = fmaf(w0.w, p0.w, acc3);
-          acc0 = fmaf(w1.x, p1.x, acc0);
-          acc1 = fmaf(w1.y, p1.y, acc1);
-          acc2 = fmaf(w1.z, p1.z, acc2);
-          acc3 = fmaf(w1.w, p1.w, acc3);
-        }
+      const float4 *wrow = reinterpret_cast<const float4 *>((ELL_LDS ? ellw_lds : p.ell_w) + woff);
+      for (int t4 = 0; t4 < len / 4; t4 += 2) {
+        const float4 w0 = wrow[t4], w1 = wrow[t4 + 1];
+        const float4 p0 = prow[t4], p1 = prow[t4 + 1];
+        acc0 = fmaf(w0.x, p0.x, acc0);
+        acc1 = fmaf(w0.y, p0.y, acc1);
+        acc2 = fmaf(w0.z, p0.z, acc2);
+        acc3 = fmaf(w0.w, p0.w, acc3);
+        acc0 = fmaf(w1.x, p1.x, acc0);
+        acc1 = fmaf(w1.y, p1.y, acc1);
+        acc2 = fmaf(w1.z, p1.z, acc2);
+        acc3 = fmaf(w1.w, p1.w, acc3);
       }
       float acc = (acc0 + acc1) + (acc2 + acc3);
       // max(val, floor) as Python evaluates it: a NaN stays a NaN (compute.py:459)
@@ -347,6 +390,7 @@ static int32_t launch_wave(const pds_stft_plan *plan, const BatchArgs &a) {
   p.out_stride = a.out_stride;
   p.win_lane = ft.d_window;
   p.tw_lane = (const float2 *)ft.d_twiddle;
+  p.tw_special = (const float2 *)ft.d_tw_special;
   p.ell_w = ft.d_ell_w;
   p.ell_meta = ft.d_ell_meta;
   p.ell_len = ft.d_ell_len;
@@ -375,14 +419,15 @@ static int32_t launch_wave(const pds_stft_plan *plan, const BatchArgs &a) {
   const size_t table_bytes = (size_t)ft.ell_wfloats * 4;
   const int target_wgs = std::max(1, 4 * MINW / WAVES);
   const size_t budget = (size_t)(160 * 1024) / target_wgs;
-  p.ell_in_lds = wave_bytes + table_bytes <= budget ? 1 : 0;
-  const size_t smem = wave_bytes + (p.ell_in_lds ? table_bytes : 0);
-  auto kern = stft_wave_kernel<N1, N2, NROWS, WAVES, MINW>;
-  static size_t attr_smem = 0;  // per instantiation
-  if (smem > attr_smem) {
+  const bool in_lds = wave_bytes + table_bytes <= budget;
+  const size_t smem = wave_bytes + (in_lds ? table_bytes : 0);
+  auto kern = in_lds ? stft_wave_kernel<N1, N2, NROWS, WAVES, MINW, true>
+                     : stft_wave_kernel<N1, N2, NROWS, WAVES, MINW, false>;
+  static size_t attr_smem[2] = {0, 0};  // per instantiation
+  if (smem > attr_smem[in_lds]) {
     PDS_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)smem));
-    attr_smem = smem;
+    attr_smem[in_lds] = smem;
   }
   int wgs_per_cu = (int)((size_t)(160 * 1024) / smem);
   wgs_per_cu = std::max(1, std::min(wgs_per_cu, target_wgs));
@@ -515,6 +560,13 @@ int32_t fast_tables_create(pds_stft_plan *plan, const double *window, const int3
   if (rc == PDS_OK) rc = upload(&ft.d_ell_woff, ell_woff.data(), ell_woff.size());
   if (rc == PDS_OK) rc = upload(&ft.d_window, win.data(), win.size());
   if (rc == PDS_OK) rc = upload(&ft.d_twiddle, tw.data(), tw.size());
+  std::vector<float> tws((size_t)n2 * 2);
+  for (int r = 0; r < n2; ++r) {
+    const double ang = -2.0 * M_PI * (double)r / (double)(2 * n2);
+    tws[2 * r] = (float)std::cos(ang);
+    tws[2 * r + 1] = (float)std::sin(ang);
+  }
+  if (rc == PDS_OK) rc = upload(&ft.d_tw_special, tws.data(), tws.size());
   if (rc != PDS_OK) return rc;
   hipDeviceProp_t prop;
   PDS_HIP(hipGetDeviceProperties(&prop, plan->device));
@@ -530,6 +582,7 @@ void fast_tables_destroy(pds_stft_plan *plan) {
   FastTables &ft = plan->fast;
   (void)hipFree(ft.d_window);
   (void)hipFree(ft.d_twiddle);
+  (void)hipFree(ft.d_tw_special);
   (void)hipFree(ft.d_ell_w);
   (void)hipFree(ft.d_ell_meta);
   (void)hipFree(ft.d_ell_len);
