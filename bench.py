@@ -27,6 +27,9 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip-level parameters)
+# HBM bytes per launch measured with rocprofv3 PMC passes (profiles/run_profile.sh), per workload:
+# FETCH_SIZE x 2 (gfx950 counts a wide coalesced read stream at half its bytes) + WRITE_SIZE
+PMC_TRAFFIC_FILE = os.path.join(ROOT, "profiles", "pmc_traffic.json")
 
 WORKLOADS = {
     # name: (config, samples per utterance, utterances per GPU)
@@ -200,6 +203,15 @@ def main():
         k_avg_s = 1e-3 * float(np.mean(kernel_ms))
         achieved = frames * bytes_per_frame / k_avg_s / 1e9
         value = world * frames * args.steps / elapsed
+        traffic = traffic_bytes = None
+        try:
+            with open(PMC_TRAFFIC_FILE) as fh:
+                rec = json.load(fh).get(args.workload)
+            if rec and rec["frames_per_launch"] == frames and not args.generic:
+                traffic_bytes = rec["hbm_bytes_per_launch"]
+                traffic = traffic_bytes / k_avg_s / 1e9
+        except (OSError, ValueError, KeyError):
+            pass
         line = {
             "metric": "frames/s (whole node) + HBM-roofline %, 40-mel fbank 16kHz 25/10ms",
             "value": value,
@@ -222,7 +234,8 @@ def main():
             },
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                "traffic_bytes_per_launch_pmc": traffic_bytes,
                 "kernel_ms_avg": 1e3 * k_avg_s, "kernel_ms_min": float(np.min(kernel_ms)),
                 "algorithmic_bytes_per_frame": bytes_per_frame,
                 "frames_per_s_per_gpu_kernel_only": frames / k_avg_s,
