@@ -94,6 +94,9 @@ int32_t pds_stft_plan_kernel_kind(const pds_stft_plan *plan);
  * d_row_off  : device, int64[B]     first output row of utterance b
  * max_frames : max over b of d_nframes[b] (sizes the launch grid; host knows it)
  * pad_left   : left reflection to use for this call, or -1 for the plan's
+ * preemph    : 0, or the coefficient of Preemphasize (reference pre.py:103-149) applied to
+ *              every utterance before framing: x'[i] = x[i] - preemph * x[i-1], x'[0] = x[0]
+ *              (what the reference's drivers do before compute_full, command_line.py:346-348)
  * d_out      : device, T[rows * out_stride]  row r, coefficient c at r * out_stride + c
  * out_stride : >= num_coeffs (lets a caller leave room for Deltas in the same rows)
  *
@@ -103,22 +106,40 @@ int32_t pds_stft_plan_kernel_kind(const pds_stft_plan *plan);
 int32_t pds_stft_batch_f32(const pds_stft_plan *plan, const float *d_signal,
                            const int64_t *d_offsets, const int64_t *d_lengths,
                            const int64_t *d_nframes, const int64_t *d_row_off, int32_t B,
-                           int64_t max_frames, int32_t pad_left, float *d_out,
+                           int64_t max_frames, int32_t pad_left, double preemph, float *d_out,
                            int64_t out_stride, void *stream);
 /* float64 signals -> float64 features, float64 arithmetic throughout (the reference's
  * internal precision, compute.py:403-414); always the generic kernel */
 int32_t pds_stft_batch_f64(const pds_stft_plan *plan, const double *d_signal,
                            const int64_t *d_offsets, const int64_t *d_lengths,
                            const int64_t *d_nframes, const int64_t *d_row_off, int32_t B,
-                           int64_t max_frames, int32_t pad_left, double *d_out,
+                           int64_t max_frames, int32_t pad_left, double preemph, double *d_out,
                            int64_t out_stride, void *stream);
 /* float32 input through the generic direct-DFT kernel regardless of N (cross-check of
  * the fused kernel; also what non-power-of-two N uses) */
 int32_t pds_stft_batch_f32_generic(const pds_stft_plan *plan, const float *d_signal,
                                    const int64_t *d_offsets, const int64_t *d_lengths,
                                    const int64_t *d_nframes, const int64_t *d_row_off,
-                                   int32_t B, int64_t max_frames, int32_t pad_left,
+                                   int32_t B, int64_t max_frames, int32_t pad_left, double preemph,
                                    float *d_out, int64_t out_stride, void *stream);
+
+/* ---------------------------------------------------------------------------------
+ * Pre-processors as separate passes (reference pre.py:67-149); `preemph` above fuses the
+ * first one into the frame load instead.
+ * pds_preemphasize: per utterance of a packed buffer (offsets/lengths as in pds_stft_batch),
+ *   out[i] = in[i] - coeff * in[i-1], out[0] = in[0]; float64 intermediate, d_out != d_in.
+ * pds_dither: out[i] = in[i] + N(0, coeff^2) noise from a counter-based generator
+ *   (Philox4x32-10 keyed by `seed`, Box-Muller); d_out may equal d_in.
+ * --------------------------------------------------------------------------------- */
+int32_t pds_preemphasize_f32(const float *d_in, const int64_t *d_offsets, const int64_t *d_lengths,
+                             int32_t B, int64_t max_len, double coeff, float *d_out, void *stream);
+int32_t pds_preemphasize_f64(const double *d_in, const int64_t *d_offsets,
+                             const int64_t *d_lengths, int32_t B, int64_t max_len, double coeff,
+                             double *d_out, void *stream);
+int32_t pds_dither_f32(const float *d_in, int64_t total, double coeff, uint64_t seed, float *d_out,
+                       void *stream);
+int32_t pds_dither_f64(const double *d_in, int64_t total, double coeff, uint64_t seed,
+                       double *d_out, void *stream);
 
 /* ---------------------------------------------------------------------------------
  * Deltas.apply (reference post.py:462-491): correlation along a "time" axis of a

@@ -15,8 +15,8 @@ arguments and JSON ``alias`` configuration surface are the reference's, so
 works as it does with ``pydrobert.speech``.  There is no CPU fallback: computing
 without the built library or without a HIP device raises.
 """
-from . import alias, compute, config, filters, post, scales, util  # noqa: F401
+from . import alias, compute, config, filters, post, pre, scales, util  # noqa: F401
 from ._native import LIB_PATH, NativeError  # noqa: F401
 
-__all__ = ["alias", "compute", "config", "filters", "post", "scales", "util"]
+__all__ = ["alias", "compute", "config", "filters", "post", "pre", "scales", "util"]
 __version__ = "0.1.0"

@@ -46,6 +46,7 @@ _BATCH_ARGS = [
     c_int32,  # B
     c_int64,  # max_frames
     c_int32,  # pad_left
+    c_double,  # preemph
     c_void_p,  # d_out
     c_int64,  # out_stride
     c_void_p,  # stream
@@ -80,6 +81,10 @@ SIGNATURES = {
     "pds_stft_batch_f32": (c_int32, _BATCH_ARGS),
     "pds_stft_batch_f64": (c_int32, _BATCH_ARGS),
     "pds_stft_batch_f32_generic": (c_int32, _BATCH_ARGS),
+    "pds_preemphasize_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_int64, c_double, c_void_p, c_void_p]),
+    "pds_preemphasize_f64": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_int64, c_double, c_void_p, c_void_p]),
+    "pds_dither_f32": (c_int32, [c_void_p, c_int64, c_double, ctypes.c_uint64, c_void_p, c_void_p]),
+    "pds_dither_f64": (c_int32, [c_void_p, c_int64, c_double, ctypes.c_uint64, c_void_p, c_void_p]),
     "pds_deltas_f32": (c_int32, _DELTAS_ARGS),
     "pds_deltas_f64": (c_int32, _DELTAS_ARGS),
     "pds_deltas_rows_f32": (

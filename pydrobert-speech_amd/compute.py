@@ -388,8 +388,13 @@ class ShortTimeFourierTransformFrameComputer(LinearFilterBankFrameComputer):
             d_meta=torch.from_numpy(np.ascontiguousarray(meta)).to(device),
         )
 
-    def launch(self, signal, layout: "PackedLayout", out=None, pad_left=None, generic=False):
+    def launch(self, signal, layout: "PackedLayout", out=None, pad_left=None, generic=False,
+               preemphasis: float = 0.0):
         """Queue the batch kernel for `layout` on the current stream; returns the output
+
+        `preemphasis`: coefficient of :class:`pydrobert_speech_amd.pre.Preemphasize` to apply
+        to every utterance while its frames are loaded (0 = none) -- equivalent to, and one
+        pass over the signal cheaper than, pre-emphasising first.
 
         `signal`: contiguous 1-D float32/float64 GPU tensor; `out`: optional
         ``(>= total_rows, >= num_coeffs)`` tensor of the same dtype with unit column
@@ -438,6 +443,7 @@ class ShortTimeFourierTransformFrameComputer(LinearFilterBankFrameComputer):
                     hi - lo,
                     int(layout.nframes[lo:hi].max()),
                     pad,
+                    float(preemphasis),
                     out.data_ptr(),
                     out.stride(0),
                     stream,
@@ -446,14 +452,15 @@ class ShortTimeFourierTransformFrameComputer(LinearFilterBankFrameComputer):
         return out
 
     def compute_packed(self, signal, offsets, lengths, nframes=None, pad_left=None, out=None,
-                       generic=False):
+                       generic=False, preemphasis: float = 0.0):
         """:func:`prepare_layout` + :func:`launch` in one call
 
         Returns ``(feats, row_offsets)``: the ``(total_rows, num_coeffs)`` GPU tensor and
         the ``B + 1`` host row offsets of the utterances inside it.
         """
         layout = self.prepare_layout(offsets, lengths, nframes, device=signal.device)
-        feats = self.launch(signal, layout, out=out, pad_left=pad_left, generic=generic)
+        feats = self.launch(signal, layout, out=out, pad_left=pad_left, generic=generic,
+                            preemphasis=preemphasis)
         return feats, layout.row_offsets
 
     @staticmethod
@@ -491,8 +498,8 @@ class ShortTimeFourierTransformFrameComputer(LinearFilterBankFrameComputer):
             raise ValueError("signal must be 1-dimensional")
         return self._run_host_signal(signal, self.num_frames(len(signal)), None)
 
-    def compute_full_batch(self, signals: Sequence) -> list:
-        """:func:`compute_full` of many signals in one launch
+    def compute_full_batch(self, signals: Sequence, preemphasis: float = 0.0) -> list:
+        """:func:`compute_full` of many signals in one launch (optionally pre-emphasised)
 
         `signals` is a sequence of 1-D arrays (numpy, or torch tensors already on the
         GPU) of one dtype.  Returns the list of feature matrices, in order; numpy in,
@@ -518,7 +525,7 @@ class ShortTimeFourierTransformFrameComputer(LinearFilterBankFrameComputer):
                 [np.asarray(s, dtype=self._compute_dtype(in_dtype)).reshape(-1) for s in signals]
             ) if offsets[-1] else np.zeros(0, self._compute_dtype(in_dtype))
             packed = torch.from_numpy(host).to("cuda")
-        feats, rows = self.compute_packed(packed, offsets[:-1], lengths)
+        feats, rows = self.compute_packed(packed, offsets[:-1], lengths, preemphasis=preemphasis)
         if on_gpu:
             return [feats[rows[i] : rows[i + 1]] for i in range(len(signals))]
         feats = feats.cpu().numpy()

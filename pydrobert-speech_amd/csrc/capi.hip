@@ -142,13 +142,13 @@ static int32_t check_batch(const pds_stft_plan *plan, const void *sig, const int
   pds::BatchArgs a{d_signal, d_offsets,  d_lengths,                                          \
                    d_nframes, d_row_off, B,                                                  \
                    max_frames, pad_left < 0 ? plan->d.pad_left : pad_left,                   \
-                   d_out,    out_stride, (hipStream_t)stream};                               \
+                   preemph,  d_out,    out_stride, (hipStream_t)stream};                               \
   return LAUNCH(plan, a);
 
 int32_t pds_stft_batch_f32(const pds_stft_plan *plan, const float *d_signal,
                            const int64_t *d_offsets, const int64_t *d_lengths,
                            const int64_t *d_nframes, const int64_t *d_row_off, int32_t B,
-                           int64_t max_frames, int32_t pad_left, float *d_out,
+                           int64_t max_frames, int32_t pad_left, double preemph, float *d_out,
                            int64_t out_stride, void *stream) {
   PDS_BATCH_BODY((plan->fast.kind ? pds::launch_stft_fast_f32 : pds::launch_stft_generic_f32))
 }
@@ -157,14 +157,14 @@ int32_t pds_stft_batch_f32_generic(const pds_stft_plan *plan, const float *d_sig
                                    const int64_t *d_offsets, const int64_t *d_lengths,
                                    const int64_t *d_nframes, const int64_t *d_row_off,
                                    int32_t B, int64_t max_frames, int32_t pad_left,
-                                   float *d_out, int64_t out_stride, void *stream) {
+                                   double preemph, float *d_out, int64_t out_stride, void *stream) {
   PDS_BATCH_BODY(pds::launch_stft_generic_f32)
 }
 
 int32_t pds_stft_batch_f64(const pds_stft_plan *plan, const double *d_signal,
                            const int64_t *d_offsets, const int64_t *d_lengths,
                            const int64_t *d_nframes, const int64_t *d_row_off, int32_t B,
-                           int64_t max_frames, int32_t pad_left, double *d_out,
+                           int64_t max_frames, int32_t pad_left, double preemph, double *d_out,
                            int64_t out_stride, void *stream) {
   PDS_BATCH_BODY(pds::launch_stft_generic_f64)
 }

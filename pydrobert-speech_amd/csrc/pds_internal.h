@@ -60,6 +60,7 @@ struct BatchArgs {
   int32_t B;
   int64_t max_frames;
   int32_t pad_left;
+  double preemph;
   void *d_out;
   int64_t out_stride;
   hipStream_t stream;

@@ -52,7 +52,7 @@ struct FastParams {
   const int32_t *ell_woff;  // [slots] start of the slot's rows inside ell_w (floats)
   int ell_wfloats, ell_slots, ell_meta_pad;  // meta_pad: ints, multiple of 4
   int L, S, pad_left, include_energy, use_power, use_log;
-  float log_floor, inv_L;
+  float log_floor, inv_L, preemph;
   int chunks_per_utt, num_utts;
 };
 
@@ -100,7 +100,8 @@ struct WaveGeom {
 };
 
 // ELL_LDS: the filter weight rows are staged in LDS (else read from global memory through L1/L2)
-template <int N1, int N2, int NROWS, int WAVES, int MINW, bool ELL_LDS>
+// PRE: pre-emphasis x[i] - c x[i-1] (reference pre.py:146) applied while loading the frame
+template <int N1, int N2, int NROWS, int WAVES, int MINW, bool ELL_LDS, bool PRE>
 __global__ __launch_bounds__(WAVES * 64, MINW) void stft_wave_kernel(const FastParams p) {
   using G = WaveGeom<N1, N2, NROWS>;
   constexpr int N = G::N, H1 = G::H1, RS = G::RS, NB = G::NB, PSTR = G::PSTR;
@@ -165,7 +166,7 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void stft_wave_kernel(const FastP
     int64_t t = tb + g;
     int start = start0 + gS;
     int wmode = 0;
-    if (!(tb + G::GROUPS <= nfr && start0 >= 0 &&
+    if (!(tb + G::GROUPS <= nfr && start0 >= (PRE ? 1 : 0) &&
           start0 + (G::GROUPS - 1) * S + NROWS * N2 <= n)) {
       valid = tb + g < nfr;
       t = valid ? tb + g : nfr - 1;
@@ -184,6 +185,26 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void stft_wave_kernel(const FastP
       const float *xp = x + (start + r);
 #pragma unroll
       for (int n1 = 0; n1 < NROWS; ++n1) a[n1] = xp[n1 * N2];
+      if constexpr (PRE) {
+        // predecessor of lane r's sample: lane r - 1 of the same row, or (r = 0) the last lane
+        // of the previous row.  With 16 lanes per frame a lane group is one DPP row and
+        // row_ror:1 delivers both; other group sizes load the predecessor.
+        if constexpr (N2 == 16) {
+          float carry = 0.0f;
+          if (r == 0) carry = xp[-1];
+#pragma unroll
+          for (int n1 = 0; n1 < NROWS; ++n1) {
+            const float rot = __int_as_float(__builtin_amdgcn_update_dpp(
+                0, __float_as_int(a[n1]), 0x121 /* row_ror:1 */, 0xf, 0xf, false));
+            const float prev = r == 0 ? carry : rot;
+            carry = rot;
+            a[n1] = fmaf(-p.preemph, prev, a[n1]);
+          }
+        } else {
+#pragma unroll
+          for (int n1 = 0; n1 < NROWS; ++n1) a[n1] = fmaf(-p.preemph, xp[n1 * N2 - 1], a[n1]);
+        }
+      }
     } else {
       float *tmp = wbase;
 #pragma unroll 1
@@ -198,6 +219,7 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void stft_wave_kernel(const FastP
             i = (int)reflect_index((int64_t)i, (int64_t)n);
           }
           v = x[i];
+          if (PRE && i > 0) v = fmaf(-p.preemph, x[i - 1], v);
         }
         tmp[n1 * 64 + lane] = v;
       }
@@ -420,14 +442,21 @@ static int32_t launch_wave(const pds_stft_plan *plan, const BatchArgs &a) {
   const int target_wgs = std::max(1, 4 * MINW / WAVES);
   const size_t budget = (size_t)(160 * 1024) / target_wgs;
   const bool in_lds = wave_bytes + table_bytes <= budget;
+  const bool pre = a.preemph != 0.0;
+  // the fused pre-emphasis variant exists for LDS-resident tables only; the rare other case
+  // (dense complex bank at N >= 1024 plus pre-emphasis) takes the direct-DFT kernel
+  if (pre && !in_lds) return launch_stft_generic_f32(plan, a);
+  p.preemph = (float)a.preemph;
   const size_t smem = wave_bytes + (in_lds ? table_bytes : 0);
-  auto kern = in_lds ? stft_wave_kernel<N1, N2, NROWS, WAVES, MINW, true>
-                     : stft_wave_kernel<N1, N2, NROWS, WAVES, MINW, false>;
-  static size_t attr_smem[2] = {0, 0};  // per instantiation
-  if (smem > attr_smem[in_lds]) {
+  auto kern = pre      ? stft_wave_kernel<N1, N2, NROWS, WAVES, MINW, true, true>
+              : in_lds ? stft_wave_kernel<N1, N2, NROWS, WAVES, MINW, true, false>
+                       : stft_wave_kernel<N1, N2, NROWS, WAVES, MINW, false, false>;
+  static size_t attr_smem[3] = {0, 0, 0};  // per instantiation
+  const int which = pre ? 2 : (in_lds ? 1 : 0);
+  if (smem > attr_smem[which]) {
     PDS_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)smem));
-    attr_smem[in_lds] = smem;
+    attr_smem[which] = smem;
   }
   int wgs_per_cu = (int)((size_t)(160 * 1024) / smem);
   wgs_per_cu = std::max(1, std::min(wgs_per_cu, target_wgs));

@@ -39,7 +39,7 @@ __global__ __launch_bounds__(64 * FPB) void stft_generic_kernel(
     const typename Tw<T>::type *__restrict__ tw, const int32_t *__restrict__ row_ptr,
     const int32_t *__restrict__ col, const T *__restrict__ val, T *__restrict__ out,
     int64_t out_stride, int L, int S, int N, int num_bins, int pad_left, int F, int use_power,
-    int use_log, int include_energy, T log_floor) {
+    int use_log, int include_energy, T log_floor, T preemph) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int b = blockIdx.y;
@@ -55,7 +55,9 @@ __global__ __launch_bounds__(64 * FPB) void stft_generic_kernel(
   const int64_t start = t * S - pad_left;
   T e = 0;
   for (int j = lane; j < L; j += 64) {
-    const T s = x[reflect_index(start + j, n)];
+    const int64_t i = reflect_index(start + j, n);
+    T s = x[i];
+    if (preemph != (T)0 && i > 0) s -= preemph * x[i - 1];  // pre.py:146 before framing
     e += s * s;
     xw[j] = s * window[j];
   }
@@ -107,7 +109,8 @@ static int32_t launch_one(const pds_stft_plan *p, const BatchArgs &a, const T *w
                      a.d_offsets, a.d_lengths, a.d_nframes, a.d_row_off, window, tw,
                      p->d_row_ptr, p->d_col, val, (T *)a.d_out, a.out_stride, p->d.frame_length,
                      p->d.frame_shift, p->d.dft_size, p->num_bins, a.pad_left, p->d.num_filts,
-                     p->d.use_power, p->d.use_log, p->d.include_energy, (T)p->d.log_floor);
+                     p->d.use_power, p->d.use_log, p->d.include_energy, (T)p->d.log_floor,
+                     (T)a.preemph);
   PDS_HIP(hipGetLastError());
   return PDS_OK;
 }

@@ -98,3 +98,8 @@ def assert_features_close(got, want, rtol, atol, what=""):
         what, int(bad.sum()), float(err.max()), np.argwhere(bad)[:5].tolist(),
         got[bad][:5].tolist(), want[bad][:5].tolist(),
     )
+
+
+@pytest.fixture(scope="session")
+def golden_pre():
+    return _load("pre.npz")

@@ -13,6 +13,7 @@ Writes
   stft.npz              per config x length x dtype: reference compute_full output
   stream.npz            per config: reference compute_chunk/finalize outputs for fixed chunkings
   post.npz              Deltas / Standardize inputs and reference outputs
+  pre.npz               Preemphasize outputs and compute_full of pre-emphasised signals
   kaldi.npz             the reference's own known-answer fixtures (tests/data/*.pkl),
                         decoded WITHOUT unpickling (opcode walk, nothing executed)
 """
@@ -31,6 +32,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 
 from pydrobert.speech import compute as rcompute  # noqa: E402
 from pydrobert.speech import post as rpost  # noqa: E402
+from pydrobert.speech import pre as rpre  # noqa: E402
 from pydrobert.speech.alias import alias_factory_subclass_from_arg  # noqa: E402
 
 # ---------------------------------------------------------------------------------------
@@ -311,6 +313,27 @@ def main():
     post["cmvn/in3"] = x3
     post["cmvn/out/in3_axis1"] = rpost.Standardize().apply(x3, axis=1)
     np.savez_compressed(os.path.join(HERE, "post.npz"), **post)
+
+    # ---- pre-processors -------------------------------------------------------------------
+    pre = {}
+    comp = build(CONFIGS["c1_readme_fbank"])
+    for dt in ("f4", "f8"):
+        x = sig[500:4500].astype(dt)
+        pe = rpre.Preemphasize(0.97).apply(x)
+        assert pe.dtype == x.dtype
+        pre[f"preemph/out/{dt}"] = pe
+        pre[f"preemph/stft/{dt}"] = comp.compute_full(pe)
+    x2 = sig[:600].reshape(3, 200)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore", DeprecationWarning)
+        pre["preemph/out/2d_axis0"] = rpre.Preemphasize(0.5).apply(x2.copy(), axis=0)
+    pre["preemph/out/2d_last"] = rpre.Preemphasize(0.5).apply(x2.copy())
+    comp5 = build(CONFIGS["c5_gammatone64_48k"])
+    x = sig[:9000].astype("f4")
+    pre["preemph/stft/c5"] = comp5.compute_full(rpre.Preemphasize(0.9).apply(x))
+    compk = build(CONFIGS["v_fbank_8k_bartlett"])
+    pre["preemph/stft/n256"] = compk.compute_full(rpre.Preemphasize(0.97).apply(sig[:3000].astype("f4")))
+    np.savez_compressed(os.path.join(HERE, "pre.npz"), **pre)
 
     # ---- the reference's own known-answer fixtures -------------------------------------
     data = os.path.join(REF, "tests", "data")

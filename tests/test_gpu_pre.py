@@ -1,0 +1,127 @@
+"""Pre-processors on the GPU (reference pre.py) and pre-emphasis fused into the STFT kernels"""
+import json
+import warnings
+
+import numpy as np
+import pytest
+
+from pydrobert_speech_amd.alias import alias_factory_subclass_from_arg
+from pydrobert_speech_amd.compute import FrameComputer
+from pydrobert_speech_amd.pre import Dither, PreProcessor, Preemphasize
+from oracle import stft_oracle as orc
+from tests.conftest import assert_features_close
+
+pytestmark = pytest.mark.gpu
+F32 = dict(rtol=1e-4, atol=1e-5)
+
+
+def build(cfg):
+    return alias_factory_subclass_from_arg(FrameComputer, json.loads(json.dumps(cfg)))
+
+
+def test_aliases():
+    assert isinstance(alias_factory_subclass_from_arg(PreProcessor, "preemph"), Preemphasize)
+    d = alias_factory_subclass_from_arg(PreProcessor, {"name": "dithering", "coeff": 2.0})
+    assert isinstance(d, Dither) and d.coeff == 2.0
+    assert alias_factory_subclass_from_arg(PreProcessor, "preemphasis").coeff == 0.97
+
+
+def test_preemphasize_matches_reference_outputs(golden_pre, master_signal):
+    for dt in ("f4", "f8"):
+        x = master_signal[500:4500].astype(dt)
+        x.flags.writeable = False
+        got = Preemphasize(0.97).apply(x)
+        assert got.dtype == x.dtype and np.array_equal(got, golden_pre[f"preemph/out/{dt}"])
+    x2 = master_signal[:600].reshape(3, 200)
+    assert np.array_equal(Preemphasize(0.5).apply(x2), golden_pre["preemph/out/2d_last"])
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore", DeprecationWarning)
+        assert np.array_equal(Preemphasize(0.5).apply(x2, axis=0), golden_pre["preemph/out/2d_axis0"])
+    assert Preemphasize().apply(np.zeros(0, np.float32)).shape == (0,)
+    ints = (master_signal[:100]).astype(np.int16)
+    assert np.array_equal(Preemphasize(0.97).apply(ints), orc.preemphasize(ints, 0.97))
+
+
+def test_reference_property_high_frequencies_gain(master_signal):
+    # reference tests/test_pre.py:15-30
+    a = np.random.default_rng(2).random(1028)
+    A = np.abs(np.fft.rfft(a))
+    A /= A.sum()
+    b = Preemphasize().apply(a)
+    B = np.abs(np.fft.rfft(b))
+    B /= B.sum()
+    assert a.shape == b.shape and np.all(B[1028 // 4 :] > A[1028 // 4 :] * 0) and B[-100:].sum() > A[-100:].sum()
+
+
+@pytest.mark.parametrize("key,cfg_name,coeff,sl", [
+    ("preemph/stft/f4", "c1_readme_fbank", 0.97, slice(500, 4500)),
+    ("preemph/stft/c5", "c5_gammatone64_48k", 0.9, slice(0, 9000)),
+    ("preemph/stft/n256", "v_fbank_8k_bartlett", 0.97, slice(0, 3000)),
+])
+def test_fused_preemphasis_matches_reference(key, cfg_name, coeff, sl, golden_pre, golden_meta, master_signal):
+    import torch
+
+    comp = build(golden_meta["configs"][cfg_name])
+    x = master_signal[sl].astype("f4")
+    want = golden_pre[key]
+    got = comp.compute_full_batch([x], preemphasis=coeff)[0]
+    assert_features_close(got, want, what=(key, "fused"), **F32)
+    # the separate pass followed by the plain kernel, and the direct-DFT kernel with its own fusion
+    got2 = comp.compute_full(Preemphasize(coeff).apply(x))
+    assert_features_close(got2, want, what=(key, "two-pass"), **F32)
+    d = torch.from_numpy(x).cuda()
+    got3, _ = comp.compute_packed(d, [0], [len(x)], generic=True, preemphasis=coeff)
+    assert_features_close(got3.cpu().numpy(), want, what=(key, "generic fused"), **F32)
+
+
+def test_fused_preemphasis_float64(golden_pre, golden_meta, master_signal):
+    comp = build(golden_meta["configs"]["c1_readme_fbank"])
+    x = master_signal[500:4500].astype("f8")
+    got = comp.compute_full_batch([x], preemphasis=0.97)[0]
+    assert got.dtype == np.float64
+    assert_features_close(got, golden_pre["preemph/stft/f8"], rtol=1e-9, atol=1e-9)
+
+
+def test_fused_preemphasis_ragged_batch_vs_oracle(golden_meta, golden_tables):
+    from tests.conftest import oracle_params
+
+    comp = build(golden_meta["configs"]["c2_tri_mel40"])
+    p = oracle_params(golden_tables, "c2_tri_mel40")
+    rng = np.random.default_rng(8)
+    L, S = comp.frame_length, comp.frame_shift
+    sigs = [(3000 * rng.standard_normal(n)).astype("f4") for n in (L // 2 + 1, 1, 0, 3 * L, 64 * S + 5, 17 * S)]
+    got = comp.compute_full_batch(sigs, preemphasis=0.95)
+    for x, y in zip(sigs, got):
+        assert_features_close(y, orc.compute_full(orc.preemphasize(x, 0.95), p), what=len(x), **F32)
+
+
+def test_packed_preemphasis_respects_utterance_boundaries():
+    import torch
+
+    rng = np.random.default_rng(3)
+    lens = [5, 1, 0, 1000, 37]
+    offs = np.concatenate([[0], np.cumsum(lens)])[:-1] + np.arange(len(lens)) * 3  # gaps
+    buf = rng.standard_normal(int(offs[-1] + lens[-1] + 3)).astype("f4")
+    out = Preemphasize(0.9).apply_packed(torch.from_numpy(buf).cuda(), offs, lens).cpu().numpy()
+    for o, n in zip(offs, lens):
+        assert np.array_equal(out[o : o + n], orc.preemphasize(buf[o : o + n], 0.9))
+
+
+def test_dither_statistics():
+    # reference tests/test_pre.py:6-12 (statistical parity: the generator differs by design)
+    T, std = 200_000, 5
+    d = Dither(std, seed=1)
+    b = d.apply(np.zeros(T))
+    assert b.shape == (T,) and b.dtype == np.float64
+    assert np.isclose(b.std(), std, atol=3e-2) and abs(b.mean()) < 5e-2
+    # kurtosis of a normal, no duplicates between calls, reproducible with the seed
+    assert abs(((b / b.std()) ** 4).mean() - 3.0) < 0.1
+    b2 = d.apply(np.zeros(T))
+    assert not np.array_equal(b, b2)
+    assert np.array_equal(Dither(std, seed=1).apply(np.zeros(T)), b)
+    x = np.arange(9, dtype=np.float32)
+    assert Dither(0.0).apply(x).tolist() == x.tolist()
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore", DeprecationWarning)
+        y = Dither(1.0, seed=2).apply(np.zeros((4, 6)), axis=1)
+    assert y.shape == (4, 6) and np.array_equal(y[0], y[3]) and len(set(y[0].tolist())) == 6

@@ -102,3 +102,16 @@ def test_cmvn_oracle(golden_post):
     assert np.allclose(orc.cmvn_local(x, -1, stats=stats), golden_post["cmvn/out/global"], rtol=1e-12, atol=1e-12)
     x3 = golden_post["cmvn/in3"]
     assert np.allclose(orc.cmvn_local(x3, 1), golden_post["cmvn/out/in3_axis1"], rtol=1e-12, atol=1e-12)
+
+
+def test_preemphasis_oracle(golden_pre, golden_tables, master_signal):
+    for dt in ("f4", "f8"):
+        x = master_signal[500:4500].astype(dt)
+        pe = orc.preemphasize(x, 0.97)
+        assert pe.dtype == x.dtype and np.array_equal(pe, golden_pre[f"preemph/out/{dt}"])
+        p = oracle_params(golden_tables, "c1_readme_fbank")
+        tol = dict(rtol=1e-10, atol=1e-10) if dt == "f8" else dict(rtol=2e-6, atol=2e-6)
+        assert_features_close(orc.compute_full(pe, p), golden_pre[f"preemph/stft/{dt}"], **tol)
+    x2 = master_signal[:600].reshape(3, 200)
+    assert np.array_equal(orc.preemphasize(x2, 0.5), golden_pre["preemph/out/2d_last"])
+    assert np.array_equal(orc.preemphasize(x2.T, 0.5).T, golden_pre["preemph/out/2d_axis0"])
