@@ -38,6 +38,13 @@
 
 namespace pds {
 
+// Timing-only builds (tools/build_variant.sh -DPDS_ABLATE=mask) drop one stage each to see what it
+// costs; results are wrong by construction.  0 in the product build.
+#ifndef PDS_ABLATE
+#define PDS_ABLATE 0
+#endif
+__device__ __forceinline__ void keep_alive(float v) { asm volatile("" ::"v"(v)); }
+
 struct FastParams {
   const float *sig;
   const int64_t *offsets, *lengths, *nframes, *row_off;
@@ -115,8 +122,10 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void stft_wave_kernel(const FastP
   // filter table -> LDS once per workgroup (read by every wave, every iteration): per-slot
   // weight rows.  Tables too large for LDS (dense complex banks) stay in global memory and
   // come through L1/L2.
-  int *meta_lds = reinterpret_cast<int *>(smem + WAVES * (G::EXCH_F2 * 2));
+  float2 *sw_lds = reinterpret_cast<float2 *>(smem + WAVES * (G::EXCH_F2 * 2));  // [N2]
+  int *meta_lds = reinterpret_cast<int *>(sw_lds + N2);
   float *ellw_lds = reinterpret_cast<float *>(meta_lds + p.ell_meta_pad);
+  if (threadIdx.x < N2) sw_lds[threadIdx.x] = p.tw_special[threadIdx.x];
   for (int i = threadIdx.x; i < p.ell_slots * N2; i += WAVES * 64) meta_lds[i] = p.ell_meta[i];
   if constexpr (ELL_LDS)
     for (int i = threadIdx.x; i < p.ell_wfloats; i += WAVES * 64) ellw_lds[i] = p.ell_w[i];
@@ -124,6 +133,10 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void stft_wave_kernel(const FastP
   for (int i = threadIdx.x; i < WAVES * G::EXCH_F2 * 2; i += WAVES * 64) smem[i] = 0.0f;
   __syncthreads();
 
+#ifndef PDS_TABLES_PER_ITER
+#define PDS_TABLES_PER_ITER 0
+#endif
+#if !PDS_TABLES_PER_ITER
   // per-lane constants, loop invariant: window slice and inter-stage twiddles
   float win[NROWS];
   float twr[H1], twi[H1];
@@ -135,12 +148,10 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void stft_wave_kernel(const FastP
     twr[k1] = t.x;
     twi[k1] = t.y;
   }
+#endif
   const int L = p.L, S = p.S;
   const bool use_power = p.use_power != 0;
   const int col0 = p.include_energy ? 1 : 0;
-  const int gS = g * S;
-  // W_(2 N2)^r: twiddle of lane r in the distributed untangling of the even/odd-sum column
-  const float2 sw = p.tw_special[r];
 
   // work items: (utterance, chunk of GROUPS consecutive frames); the waves of a workgroup
   // take neighbouring chunks so that overlapping samples are shared through the CU's L1
@@ -164,7 +175,7 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void stft_wave_kernel(const FastP
     const int start0 = (int)(tb * S) - p.pad_left;
     bool valid = true;
     int64_t t = tb + g;
-    int start = start0 + gS;
+    int start = start0 + g * S;
     int wmode = 0;
     if (!(tb + G::GROUPS <= nfr && start0 >= (PRE ? 1 : 0) &&
           start0 + (G::GROUPS - 1) * S + NROWS * N2 <= n)) {
@@ -177,6 +188,24 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void stft_wave_kernel(const FastP
       wmode = __builtin_amdgcn_readfirstlane(__any(mode == 2) ? 2 : (__any(mode == 1) ? 1 : 0));
     }
 
+    // W_(2 N2)^r, twiddle of lane r in the distributed untangling of the even/odd-sum column:
+    // re-read from LDS every iteration rather than held in two registers per lane -- the kernel
+    // sits exactly at the 128-VGPR occupancy step
+    const float2 sw = sw_lds[r];
+#if PDS_TABLES_PER_ITER
+    // window slice and twiddles re-read every iteration (L1-resident 4 KB tables) instead of
+    // living in 55 registers
+    float win[NROWS];
+    float twr[H1], twi[H1];
+#pragma unroll
+    for (int n1 = 0; n1 < NROWS; ++n1) win[n1] = p.win_lane[r * N1 + n1];
+#pragma unroll
+    for (int k1 = 1; k1 < H1; ++k1) {
+      const float2 t = p.tw_lane[r * H1 + k1];
+      twr[k1] = t.x;
+      twi[k1] = t.y;
+    }
+#endif
     float a[N1];
     float energy = 0.0f;
     if (wmode == 0) {
@@ -184,7 +213,7 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void stft_wave_kernel(const FastP
       // window (exactly 0 there, applied with the 0 * x = 0 multiply) removes them.
       const float *xp = x + (start + r);
 #pragma unroll
-      for (int n1 = 0; n1 < NROWS; ++n1) a[n1] = xp[n1 * N2];
+      for (int n1 = 0; n1 < NROWS; ++n1) a[n1] = (PDS_ABLATE & 1) ? (float)(lane + n1) : xp[n1 * N2];
       if constexpr (PRE) {
         // predecessor of lane r's sample: lane r - 1 of the same row, or (r = 0) the last lane
         // of the previous row.  With 16 lanes per frame a lane group is one DPP row and
@@ -242,7 +271,17 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void stft_wave_kernel(const FastP
     for (int n1 = NROWS; n1 < N1; ++n1) a[n1] = 0.0f;
 
     float even_sum, odd_sum, Ar[H1], Ai[H1];
-    inl::rdft_scaled<N1>(a, even_sum, odd_sum, Ar, Ai);
+    if constexpr (PDS_ABLATE & 2) {
+      even_sum = a[0];
+      odd_sum = a[1];
+#pragma unroll
+      for (int k = 0; k < H1; ++k) {
+        Ar[k] = a[2 * k];
+        Ai[k] = a[2 * k + 1];
+      }
+    } else {
+      inl::rdft_scaled<N1>(a, even_sum, odd_sum, Ar, Ai);
+    }
 
     // transpose through LDS: row k1 of this frame's block holds column k1 for all n2; row 0
     // holds c[j] = sum_q xw[j + 2 N2 q] (j < 2 N2), the input of the multiples of N1/2
@@ -256,7 +295,12 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void stft_wave_kernel(const FastP
       float2 v;
       v.x = Ar[k1] * twr[k1] - Ai[k1] * twi[k1];
       v.y = Ar[k1] * twi[k1] + Ai[k1] * twr[k1];
-      exch[k1 * RS + r] = v;
+      if constexpr (PDS_ABLATE & 4) {
+        Ar[k1] = v.x;
+        Ai[k1] = v.y;
+      } else {
+        exch[k1 * RS + r] = v;
+      }
     }
     wave_sync();
 
@@ -269,13 +313,26 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void stft_wave_kernel(const FastP
       float zr[N2], zi[N2], Yr[N2], Yi[N2];
 #pragma unroll
       for (int j = 0; j < N2 / 2; ++j) {
-        const float4 v = row[j];
+        float4 v;
+        if constexpr (PDS_ABLATE & 4) {
+          v = make_float4(Ar[(2 * j) % H1], Ai[(2 * j) % H1], Ar[(2 * j + 1) % H1], Ai[(2 * j + 1) % H1]);
+        } else {
+          v = row[j];
+        }
         zr[2 * j] = v.x;
         zi[2 * j] = v.y;
         zr[2 * j + 1] = v.z;
         zi[2 * j + 1] = v.w;
       }
-      inl::CFFT<N2, 1>::run(zr, zi, Yr, Yi);
+      if constexpr (PDS_ABLATE & 8) {
+#pragma unroll
+        for (int k2 = 0; k2 < N2; ++k2) {
+          Yr[k2] = zr[k2];
+          Yi[k2] = zi[k2];
+        }
+      } else {
+        inl::CFFT<N2, 1>::run(zr, zi, Yr, Yi);
+      }
       if constexpr (N2 == 16) {
         // regular columns; lane 0 (q = 0) holds Y = FFT(c[2m] + i c[2m+1]) of the even/odd sums
 #pragma unroll
@@ -325,15 +382,17 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void stft_wave_kernel(const FastP
     }
     // every lane is done with the exchange area (same wave, in order): reuse it as P
     wave_sync();
+    // Stores below avoid lane predicates (each costs exec-mask bookkeeping on the scalar unit):
+    // lanes without a value of their own write to a padding slot that is zeroed afterwards.
 #pragma unroll
     for (int q = 0; q < G::CPL; ++q) {
       const int kk = q * N2 + r;
-      if (q == 0 && r == 0) {
-        if constexpr (N2 != 16) {
+      if (N2 != 16 && q == 0 && r == 0) {
 #pragma unroll
-          for (int m = 0; m <= N2; ++m) Pg[m * H1] = pw[q][m];
-        }
+        for (int m = 0; m <= N2; ++m) Pg[m * H1] = pw[q][m];
       } else {
+        // (N2 == 16: lane 0 of q = 0 writes its meaningless column to multiples of N1, all of
+        // which the special bins written next overwrite)
 #pragma unroll
         for (int k2 = 0; k2 < N2; ++k2) {
           // bin kk + N1*k2, or its mirror image when beyond N/2
@@ -343,19 +402,20 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void stft_wave_kernel(const FastP
       }
     }
     if constexpr (N2 == 16) {
-      if (r <= N2 / 2) {
-        Pg[r * H1] = sp0;
-        Pg[(N2 - r) * H1] = sp1;
-      }
+      const bool has = r <= N2 / 2;
+      Pg[has ? r * H1 : PSTR - 1] = sp0;
+      Pg[has ? (N2 - r) * H1 : PSTR - 1] = sp1;
     }
     // slots past the last bin are read (with weight 0) by the filter walk: keep them finite
-    for (int j = NB + 1 + r; j < PSTR; j += N2) Pg[j] = 0.0f;
+#pragma unroll
+    for (int j0 = 0; j0 < PSTR - NB; j0 += N2) {
+      const int j = j0 + r;
+      Pg[NB + (j < PSTR - NB ? j : PSTR - NB - 1)] = 0.0f;
+    }
     if (p.include_energy) {
 #pragma unroll
       for (int off = N2 / 2; off >= 1; off >>= 1) energy += __shfl_xor(energy, off, 64);
       if (r == 0) Pg[NB] = energy;
-    } else if (r == 0) {
-      Pg[NB] = 0.0f;
     }
     wave_sync();
 
@@ -368,7 +428,7 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void stft_wave_kernel(const FastP
       const int woff = p.ell_woff[sl] + r * (len + 4);  // + 4: conflict-free row skew
       float acc0 = 0.0f, acc1 = 0.0f, acc2 = 0.0f, acc3 = 0.0f;
       const float4 *wrow = reinterpret_cast<const float4 *>((ELL_LDS ? ellw_lds : p.ell_w) + woff);
-      for (int t4 = 0; t4 < len / 4; t4 += 2) {
+      for (int t4 = 0; t4 < ((PDS_ABLATE & 32) ? 2 : len / 4); t4 += 2) {
         const float4 w0 = wrow[t4], w1 = wrow[t4 + 1];
         const float4 p0 = prow[t4], p1 = prow[t4 + 1];
         acc0 = fmaf(w0.x, p0.x, acc0);
@@ -384,7 +444,11 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void stft_wave_kernel(const FastP
       // max(val, floor) as Python evaluates it: a NaN stays a NaN (compute.py:459)
       if (p.use_log) acc = __logf(p.log_floor > acc ? p.log_floor : acc);
       const int f = (meta >> 16) - 1;
-      if (valid && f >= 0) orow[col0 + f] = acc;
+      if constexpr (PDS_ABLATE & 64) {
+        keep_alive(acc);
+      } else {
+        if (valid && f >= 0) orow[col0 + f] = acc;
+      }
     }
     if (p.include_energy && r == 0) {
       float e = Pg[NB] * p.inv_L;
@@ -437,7 +501,7 @@ static int32_t launch_wave(const pds_stft_plan *plan, const BatchArgs &a) {
   // LDS: the waves' exchange areas, then the filter table if it leaves room for the target
   // number of resident workgroups
   p.ell_meta_pad = (ft.ell_slots * N2 + 3) / 4 * 4;
-  const size_t wave_bytes = (size_t)WAVES * G::EXCH_F2 * 8 + (size_t)p.ell_meta_pad * 4;
+  const size_t wave_bytes = (size_t)WAVES * G::EXCH_F2 * 8 + (size_t)N2 * 8 + (size_t)p.ell_meta_pad * 4;
   const size_t table_bytes = (size_t)ft.ell_wfloats * 4;
   const int target_wgs = std::max(1, 4 * MINW / WAVES);
   const size_t budget = (size_t)(160 * 1024) / target_wgs;
