@@ -32,14 +32,34 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip-level
 PMC_TRAFFIC_FILE = os.path.join(ROOT, "profiles", "pmc_traffic.json")
 
 WORKLOADS = {
-    # name: (config, samples per utterance, utterances per GPU)
+    # name: (config, samples per utterance, utterances per GPU, post-processing in the step)
+    # BASELINE.json configs[1] -- the headline workload (default)
     "fbank40_16k_25_10_b1024x10s": (
         {"name": "stft", "bank": {"name": "tri", "scaling_function": "mel", "num_filts": 40},
          "frame_length_ms": 25, "frame_shift_ms": 10, "window_function": "hanning",
          "use_power": True},
-        160000, 1024,
+        160000, 1024, None,
+    ),
+    # configs[2] per GPU at reduced batch: 80 mel + energy, then Deltas(2) beside the statics
+    "fbank80_energy_deltas2_b1024x10s": (
+        {"name": "stft", "bank": {"name": "fbank", "num_filts": 80}, "frame_length_ms": 25,
+         "include_energy": True, "use_power": True},
+        160000, 1024, "deltas2",
+    ),
+    # configs[3]: complex Gabor bank, 64 filters
+    "gabor64_b1024x10s": (
+        {"name": "stft", "bank": {"name": "gabor", "scaling_function": "mel", "num_filts": 64},
+         "frame_length_ms": 25, "use_power": True},
+        160000, 1024, None,
+    ),
+    # configs[4] per GPU: Gammatone 64 @ 48 kHz, 20 ms frames (N = 1024), per-utterance CMVN
+    "gammatone64_48k_cmvn_b256x10s": (
+        {"name": "stft", "bank": {"name": "gammatone", "scaling_function": "mel", "num_filts": 64,
+                                  "sampling_rate": 48000}, "frame_length_ms": 20, "use_power": True},
+        480000, 256, "cmvn",
     ),
 }
+DEFAULT_WORKLOAD = "fbank40_16k_25_10_b1024x10s"
 
 
 def _cpu_worker(args):
@@ -106,7 +126,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", default="fbank40_16k_25_10_b1024x10s")
+    ap.add_argument("--workload", default=DEFAULT_WORKLOAD, choices=sorted(WORKLOADS))
     ap.add_argument("--batch", type=int, default=None, help="utterances per GPU (default: workload's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true")
@@ -126,7 +146,7 @@ def main():
     import pydrobert_speech_amd as ps
     from pydrobert_speech_amd.alias import alias_factory_subclass_from_arg
 
-    cfg, n, B = WORKLOADS[args.workload]
+    cfg, n, B, post = WORKLOADS[args.workload]
     if args.batch:
         B = args.batch
     comp = alias_factory_subclass_from_arg(ps.compute.FrameComputer, cfg)
@@ -149,10 +169,20 @@ def main():
     signal = torch.randn(B * n, generator=g, device=dev, dtype=torch.float32).mul_(3000.0)
     layout = comp.prepare_layout(np.arange(B, dtype=np.int64) * n, np.full(B, n, dtype=np.int64), device=dev)
     frames = layout.total_rows
-    out = torch.empty((frames, comp.num_coeffs), dtype=torch.float32, device=dev)
+    C = comp.num_coeffs
+    out_cols = 3 * C if post == "deltas2" else C
+    out = torch.empty((frames, out_cols), dtype=torch.float32, device=dev)
+    deltas = ps.post.Deltas(2) if post == "deltas2" else None
+    cmvn = ps.post.CMVN() if post == "cmvn" else None
+    cmvn_out = None
 
     def step():
+        nonlocal cmvn_out
         comp.launch(signal, layout, out=out, generic=args.generic)
+        if deltas is not None:  # statics were written with row stride 3C; deltas go beside them
+            deltas.apply_rows(out[:, :C], layout.row_offsets, out=out)
+        if cmvn is not None:
+            cmvn_out = cmvn.apply_rows(out, layout.row_offsets)
 
     def barrier():
         if world > 1:
@@ -180,7 +210,7 @@ def main():
 
     gather = None
     if world > 1 and not args.no_gather:
-        gathered = torch.empty((world * frames, comp.num_coeffs), dtype=torch.float32, device=dev)
+        gathered = torch.empty((world * frames, out_cols), dtype=torch.float32, device=dev)
         for _ in range(2):
             step()
             dist.all_gather_into_tensor(gathered, out)
@@ -196,10 +226,13 @@ def main():
         gather = {"value": world * frames * args.steps / el, "unit": "frames/s",
                   "ms_per_step": 1e3 * el / args.steps,
                   "collective": "all_gather_into_tensor (RCCL)",
-                  "bytes_per_rank": frames * comp.num_coeffs * 4}
+                  "bytes_per_rank": frames * out_cols * 4}
 
     if rank == 0:
-        bytes_per_frame = 4 * comp.frame_shift + 4 * comp.num_coeffs
+        # every sample read once, every output coefficient written once
+        bytes_per_frame = 4 * comp.frame_shift + 4 * out_cols
+        if cmvn is not None:
+            bytes_per_frame += 4 * C + 8 * C  # second read of the features + float64 result
         k_avg_s = 1e-3 * float(np.mean(kernel_ms))
         achieved = frames * bytes_per_frame / k_avg_s / 1e9
         value = world * frames * args.steps / elapsed
@@ -213,7 +246,8 @@ def main():
         except (OSError, ValueError, KeyError):
             pass
         line = {
-            "metric": "frames/s (whole node) + HBM-roofline %, 40-mel fbank 16kHz 25/10ms",
+            "metric": "frames/s (whole node) + HBM-roofline %, 40-mel fbank 16kHz 25/10ms"
+            if args.workload == DEFAULT_WORKLOAD else f"frames/s ({args.workload})",
             "value": value,
             "unit": "frames/s",
             "n_gpus": world,
@@ -227,7 +261,7 @@ def main():
             "data": "synthetic",
             "config": {
                 "workload": args.workload, "utterances_per_gpu": B, "samples_per_utterance": n,
-                "frames_per_gpu_per_step": frames, "num_coeffs": comp.num_coeffs,
+                "frames_per_gpu_per_step": frames, "num_coeffs": comp.num_coeffs, "post": post,
                 "frame_length": comp.frame_length, "frame_shift": comp.frame_shift,
                 "dft_size": comp.dft_size, "parallelism": f"utterance-sharded x{world}",
                 "kernel": "generic-direct-dft" if (args.generic or not comp.kernel_kind) else "fused-fft",

@@ -41,6 +41,27 @@ def _stream(torch, tensor):
     return torch.cuda.current_stream(tensor.device).cuda_stream
 
 
+_ROWS_META = {}  # one entry: the device copy of the last ragged-row description used
+
+
+def _rows_meta(row_offsets, device):
+    """Device ``int64[2][B]`` (first row, row count) of a packed ragged batch + host row counts
+
+    Repeated calls with the same `row_offsets` array (a pipeline processing batch after batch
+    of one geometry) reuse the device copy instead of a host-to-device transfer per launch.
+    """
+    torch = _native.require_device()
+    rows = np.ascontiguousarray(row_offsets, dtype=np.int64)
+    key = (rows.tobytes(), str(device))
+    hit = _ROWS_META.get("entry")
+    if hit is None or hit[0] != key:
+        nrows = np.diff(rows)
+        meta = torch.from_numpy(np.stack([rows[:-1], nrows])).to(device)
+        hit = (key, meta, nrows)
+        _ROWS_META["entry"] = hit
+    return hit[1], hit[2]
+
+
 # ------------------------------------------------------------------ Standardize ------
 
 
@@ -208,13 +229,12 @@ class Standardize(PostProcessor):
             raise ValueError("feats must be a 2-D float32 GPU tensor")
         if feats.stride(1) != 1:
             feats = feats.contiguous()
-        rows = np.asarray(row_offsets, dtype=np.int64)
-        B, C = len(rows) - 1, feats.shape[1]
+        B, C = len(row_offsets) - 1, feats.shape[1]
         out_dtype = torch.float64 if out_dtype is None else out_dtype
         out = torch.empty(feats.shape, dtype=out_dtype, device=feats.device)
         if B <= 0 or feats.shape[0] == 0:
             return out
-        meta = torch.from_numpy(np.stack([rows[:-1], np.diff(rows)])).to(feats.device)
+        meta, _ = _rows_meta(row_offsets, feats.device)
         stats = torch.empty((B, 2, C), dtype=torch.float64, device=feats.device)
         zero_var = torch.zeros(1, dtype=torch.int32, device=feats.device)
         fn = lib.pds_cmvn_rows_f32 if out_dtype == torch.float64 else lib.pds_cmvn_rows_f32out
@@ -377,14 +397,14 @@ class Deltas(PostProcessor):
             raise ValueError("feats must be a 2-D float32 GPU tensor")
         if feats.stride(1) != 1:
             feats = feats.contiguous()
-        rows = np.asarray(row_offsets, dtype=np.int64)
-        B, F, K = len(rows) - 1, feats.shape[1], self.num_deltas
+        # `feats` may be a column slice of `out` (statics already in place): the kernel then only
+        # adds the delta columns, in place
+        B, F, K = len(row_offsets) - 1, feats.shape[1], self.num_deltas
         if out is None:
             out = torch.empty((feats.shape[0], (K + 1) * F), dtype=torch.float32, device=feats.device)
         if B <= 0 or feats.shape[0] == 0:
             return out
-        nrows = np.diff(rows)
-        meta = torch.from_numpy(np.stack([rows[:-1], nrows])).to(feats.device)
+        meta, nrows = _rows_meta(row_offsets, feats.device)
         d_filts, d_offs = self._filters_on(feats.device)
         with torch.cuda.device(feats.device):
             for lo in range(0, B, 65535):

@@ -141,3 +141,65 @@ def test_rows_variants_match_per_utterance_apply():
     for b in range(len(lens2)):
         want = orc.cmvn_local(feats2[rows2[b] : rows2[b + 1]], axis=-1)
         assert np.allclose(got[rows2[b] : rows2[b + 1]], want, rtol=1e-9, atol=1e-9)
+
+
+def test_statics_and_deltas_share_one_buffer():
+    # the pipeline layout of BASELINE.json configs[2]: the STFT kernel writes the statics with a
+    # row stride that leaves room for the deltas, which are then added in place
+    import json
+
+    import torch
+
+    from pydrobert_speech_amd.alias import alias_factory_subclass_from_arg
+    from pydrobert_speech_amd.compute import FrameComputer
+
+    comp = alias_factory_subclass_from_arg(FrameComputer, json.loads(json.dumps(
+        {"name": "stft", "bank": {"name": "fbank", "num_filts": 80}, "frame_length_ms": 25,
+         "include_energy": True, "use_power": True})))
+    rng = np.random.default_rng(12)
+    lens = [16000, 4000, 250, 9000]
+    sigs = [(3000 * rng.standard_normal(n)).astype("f4") for n in lens]
+    offs = np.concatenate([[0], np.cumsum(lens)])
+    x = torch.from_numpy(np.concatenate(sigs)).cuda()
+    layout = comp.prepare_layout(offs[:-1], lens)
+    C = comp.num_coeffs
+    buf = torch.full((layout.total_rows, 3 * C), float("nan"), dtype=torch.float32, device="cuda")
+    comp.launch(x, layout, out=buf)
+    d = Deltas(2)
+    res = d.apply_rows(buf[:, :C], layout.row_offsets, out=buf)
+    assert res.data_ptr() == buf.data_ptr() and torch.isfinite(buf).all()
+    got = buf.cpu().numpy()
+    want_static = comp.compute_full_batch(sigs)
+    for b in range(len(lens)):
+        lo, hi = layout.row_offsets[b], layout.row_offsets[b + 1]
+        assert np.array_equal(got[lo:hi, :C], want_static[b])
+        want = orc.deltas(want_static[b], axis=0, num_deltas=2, target_axis=1)
+        assert np.allclose(got[lo:hi], want, rtol=1e-6, atol=1e-6)
+    # second call with the same geometry reuses the cached row description
+    d.apply_rows(buf[:, :C], layout.row_offsets, out=buf)
+
+
+def test_hip_graph_capture_of_the_batch_launch():
+    # launch() allocates nothing and never synchronises: it can be captured into a HIP graph
+    import json
+
+    import torch
+
+    from pydrobert_speech_amd.alias import alias_factory_subclass_from_arg
+    from pydrobert_speech_amd.compute import FrameComputer
+
+    comp = alias_factory_subclass_from_arg(FrameComputer, {"name": "stft", "bank": "fbank", "use_power": True})
+    n, B = 16000, 8
+    x = 3000 * torch.randn(B * n, device="cuda")
+    layout = comp.prepare_layout(np.arange(B) * n, np.full(B, n))
+    out = torch.empty((layout.total_rows, comp.num_coeffs), device="cuda")
+    comp.launch(x, layout, out=out)  # warm up (plan creation, function attributes)
+    eager = out.clone()
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        comp.launch(x, layout, out=out)
+    x.mul_(2.0)
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.allclose(out, eager + 2 * np.log(2.0), atol=2e-4)
