@@ -166,11 +166,14 @@ int32_t pds_deltas_f64(const double *d_in, int64_t outer, int64_t time, int64_t 
                        int64_t out_so, int64_t out_st, int64_t out_si, void *stream);
 /* ragged batch of [time_b, inner] feature matrices stored row-wise in one buffer (the
  * layout pds_stft_batch writes): utterance b occupies rows d_row_off[b] .. + d_nrows[b];
- * deltas never cross an utterance boundary.  in/out strides are per row. */
+ * deltas never cross an utterance boundary.  in/out strides are per row; `halo` is the reach
+ * of the longest filter, (len - 1) / 2.  d_in may be the first `inner` columns of d_out
+ * (d_in == d_out, equal strides): the statics then stay where they are. */
 int32_t pds_deltas_rows_f32(const float *d_in, int64_t in_stride, const int64_t *d_row_off,
                             const int64_t *d_nrows, int32_t B, int64_t max_rows,
                             int32_t inner, const double *d_filts, const int32_t *d_filt_off,
-                            int32_t K, float *d_out, int64_t out_stride, void *stream);
+                            int32_t K, int32_t halo, float *d_out, int64_t out_stride,
+                            void *stream);
 
 /* ---------------------------------------------------------------------------------
  * Standardize / CMVN (reference post.py:193-212 accumulate, 250-295 apply) on a tensor

@@ -66,34 +66,47 @@ static int32_t launch_deltas(const T *d_in, int64_t outer, int64_t time, int64_t
   return PDS_OK;
 }
 
-// ragged rows: grid (row tiles, utterance); thread = (row in tile, coefficient)
+// ragged rows: grid (row tiles, utterance).  A block stages its rows plus the stencil halo in
+// LDS once (edge clamping resolved there), then every thread produces the K delta values of its
+// (row, coefficient) elements from LDS: HBM sees each static once and each delta once.
 __global__ __launch_bounds__(256) void deltas_rows_kernel(
     const float *__restrict__ in, int64_t in_stride, const int64_t *__restrict__ row_off,
     const int64_t *__restrict__ nrows, int inner, const double *__restrict__ filts,
-    const int32_t *__restrict__ filt_off, int K, float *__restrict__ out, int64_t out_stride,
-    int rows_per_block) {
+    const int32_t *__restrict__ filt_off, int K, int halo, float *__restrict__ out,
+    int64_t out_stride, int rows_per_block, int copy_statics) {
+  extern __shared__ float tile[];  // [(rows_per_block + 2 halo)][inner]
   const int b = blockIdx.y;
   const int64_t T = nrows[b];
   const int64_t t0 = (int64_t)blockIdx.x * rows_per_block;
   if (t0 >= T) return;
   const float *src = in + row_off[b] * in_stride;
   float *dst = out + row_off[b] * out_stride;
-  const int items = rows_per_block * inner;
+  const float inv_inner = 1.0f / (float)inner;
+  const int staged = (rows_per_block + 2 * halo) * inner;
+  for (int e = threadIdx.x; e < staged; e += blockDim.x) {
+    const int lr = (int)(((float)e + 0.5f) * inv_inner);
+    const int i = e - lr * inner;
+    int64_t t = t0 - halo + lr;
+    t = t < 0 ? 0 : (t >= T ? T - 1 : t);  // "edge" padding (post.py:447)
+    tile[e] = src[t * in_stride + i];
+  }
+  __syncthreads();
+  const int64_t left = T - t0;
+  const int rows = left < rows_per_block ? (int)left : rows_per_block;
+  const int items = rows * inner;
   for (int e = threadIdx.x; e < items; e += blockDim.x) {
-    const int64_t t = t0 + e / inner;
-    const int i = e % inner;
-    if (t >= T) break;
-    dst[t * out_stride + i] = src[t * in_stride + i];
+    const int lr = (int)(((float)e + 0.5f) * inv_inner);
+    const int i = e - lr * inner;
+    float *orow = dst + (t0 + lr) * out_stride + i;
+    const float *col = tile + (lr + halo) * inner + i;
+    if (copy_statics) orow[0] = col[0];
     for (int k = 1; k <= K; ++k) {
       const int lo = filt_off[k - 1], len = filt_off[k] - lo;
       const int M = (len - 1) / 2;
       double acc = 0.0;
-      for (int j = 0; j < len; ++j) {
-        int64_t tt = t + j - M;
-        tt = tt < 0 ? 0 : (tt >= T ? T - 1 : tt);
-        acc = __dadd_rn(acc, __dmul_rn(filts[lo + j], (double)src[tt * in_stride + i]));
-      }
-      dst[t * out_stride + (int64_t)k * inner + i] = (float)acc;
+      for (int j = 0; j < len; ++j)
+        acc = __dadd_rn(acc, __dmul_rn(filts[lo + j], (double)col[(j - M) * inner]));
+      orow[(int64_t)k * inner] = (float)acc;
     }
   }
 }
@@ -293,7 +306,8 @@ int32_t pds_deltas_f64(const double *d_in, int64_t outer, int64_t time, int64_t 
 int32_t pds_deltas_rows_f32(const float *d_in, int64_t in_stride, const int64_t *d_row_off,
                             const int64_t *d_nrows, int32_t B, int64_t max_rows,
                             int32_t inner, const double *d_filts, const int32_t *d_filt_off,
-                            int32_t K, float *d_out, int64_t out_stride, void *stream) {
+                            int32_t K, int32_t halo, float *d_out, int64_t out_stride,
+                            void *stream) {
   if (B < 0 || max_rows < 0 || inner <= 0 || K < 0)
     return pds::invalid_post("deltas_rows: bad size");
   if (B == 0 || max_rows == 0) return PDS_OK;
@@ -302,13 +316,17 @@ int32_t pds_deltas_rows_f32(const float *d_in, int64_t in_stride, const int64_t 
     return pds::invalid_post("deltas_rows: null pointer");
   if (in_stride < inner || out_stride < (int64_t)(K + 1) * inner)
     return pds::invalid_post("deltas_rows: stride too small");
-  int rows_per_block = 1024 / inner;
-  if (rows_per_block < 1) rows_per_block = 1;
+  if (halo < 0) return pds::invalid_post("deltas_rows: negative halo");
+  int rows_per_block = (24 * 1024 / 4) / inner - 2 * halo;  // ~24 KB of LDS per block
   if (rows_per_block > 64) rows_per_block = 64;
+  if (rows_per_block < 1) return pds::invalid_post("deltas_rows: rows too wide for the LDS tile");
+  const size_t smem = (size_t)(rows_per_block + 2 * halo) * inner * sizeof(float);
   dim3 grid((unsigned)((max_rows + rows_per_block - 1) / rows_per_block), (unsigned)B);
-  hipLaunchKernelGGL(pds::deltas_rows_kernel, grid, dim3(256), 0, (hipStream_t)stream, d_in,
-                     in_stride, d_row_off, d_nrows, inner, d_filts, d_filt_off, K, d_out,
-                     out_stride, rows_per_block);
+  // statics already in place when the input IS the output buffer's first columns
+  const int copy_statics = !(d_in == d_out && in_stride == out_stride);
+  hipLaunchKernelGGL(pds::deltas_rows_kernel, grid, dim3(256), smem, (hipStream_t)stream, d_in,
+                     in_stride, d_row_off, d_nrows, inner, d_filts, d_filt_off, K, halo, d_out,
+                     out_stride, rows_per_block, copy_statics);
   PDS_HIP(hipGetLastError());
   return PDS_OK;
 }

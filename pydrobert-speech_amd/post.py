@@ -412,7 +412,8 @@ class Deltas(PostProcessor):
                 rc = lib.pds_deltas_rows_f32(
                     feats.data_ptr(), feats.stride(0), meta[0, lo:].data_ptr(),
                     meta[1, lo:].data_ptr(), hi - lo, int(nrows[lo:hi].max()), F,
-                    d_filts.data_ptr(), d_offs.data_ptr(), K, out.data_ptr(), out.stride(0),
+                    d_filts.data_ptr(), d_offs.data_ptr(), K, (len(self._filts[-1]) - 1) // 2,
+                    out.data_ptr(), out.stride(0),
                     _stream(torch, feats),
                 )
                 _native.check(rc, "pds_deltas_rows")
