@@ -131,6 +131,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true")
     ap.add_argument("--generic", action="store_true", help="force the direct-DFT kernel")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="nccl (= RCCL, one GPU per rank) or gloo (rehearsal: every rank on GPU 0, no gather)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -158,11 +160,18 @@ def main():
     import torch
     import torch.distributed as dist
 
+    if args.backend == "gloo":
+        local_rank = 0  # rehearsal of the multi-rank control flow on a one-GPU box
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group("gloo")
+            args.no_gather = True
+    red_dev = dev if args.backend == "nccl" else torch.device("cpu")
 
     # synthetic batch: x = 3000 N(0,1), float32, seeded per rank; generated on the device
     g = torch.Generator(device=dev).manual_seed(1234 + rank)
@@ -203,13 +212,12 @@ def main():
     elapsed = time.perf_counter() - t0
     kernel_ms = [a.elapsed_time(b) for a, b in evs]
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     finite = bool(torch.isfinite(out).all().item())
 
-    gather = None
-    if world > 1 and not args.no_gather:
+    def timed_gather():
         gathered = torch.empty((world * frames, out_cols), dtype=torch.float32, device=dev)
         for _ in range(2):
             step()
@@ -220,13 +228,21 @@ def main():
             step()
             dist.all_gather_into_tensor(gathered, out)
         barrier()
-        t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+        t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         el = float(t.item())
         gather = {"value": world * frames * args.steps / el, "unit": "frames/s",
                   "ms_per_step": 1e3 * el / args.steps,
                   "collective": "all_gather_into_tensor (RCCL)",
                   "bytes_per_rank": frames * out_cols * 4}
+        return gather
+
+    gather = None
+    if world > 1 and not args.no_gather:
+        try:
+            gather = timed_gather()
+        except Exception as exc:  # the headline number must survive a failing optional leg
+            gather = {"error": repr(exc)[:200]}
 
     if rank == 0:
         # every sample read once, every output coefficient written once
