@@ -61,6 +61,7 @@ struct FastParams {
   int L, S, pad_left, include_energy, use_power, use_log;
   float log_floor, inv_L, preemph;
   int chunks_per_utt, num_utts;
+  int step_utts, step_chunks;  // (grid waves) / chunks_per_utt and (grid waves) % chunks_per_utt
 };
 
 // v_mul_legacy_f32: IEEE multiply except that 0 * x = 0 for every x (NaN and Inf included)
@@ -153,18 +154,22 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void stft_wave_kernel(const FastP
   const bool use_power = p.use_power != 0;
   const int col0 = p.include_energy ? 1 : 0;
 
-  // work items: (utterance, chunk of GROUPS consecutive frames); the waves of a workgroup
-  // take neighbouring chunks so that overlapping samples are shared through the CU's L1
-  const int stride = gridDim.x * WAVES;
+  // work items: (utterance, chunk of GROUPS consecutive frames), dealt round-robin to all waves
+  // of the grid: the waves of a workgroup take neighbouring chunks, so overlapping samples are
+  // shared through the CU's L1.  The step to a wave's next item is a precomputed (utterances,
+  // chunks) pair -- scalar instructions compete with vector ones for issue slots, so the
+  // bookkeeping per item is kept to a handful of them.
   int b = 0;
-  for (int chunk = blockIdx.x * WAVES + wave;; chunk += stride) {
-    while (chunk >= p.chunks_per_utt && b < p.num_utts) {
-      chunk -= p.chunks_per_utt;
-      ++b;
-    }
-    if (b >= p.num_utts) break;
+  int chunk = blockIdx.x * WAVES + wave;
+  while (chunk >= p.chunks_per_utt && b < p.num_utts) {  // once per kernel
+    chunk -= p.chunks_per_utt;
+    ++b;
+  }
+  for (; b < p.num_utts; chunk += p.step_chunks, b += p.step_utts,
+                         b += chunk >= p.chunks_per_utt ? 1 : 0,
+                         chunk -= chunk >= p.chunks_per_utt ? p.chunks_per_utt : 0) {
     const int64_t nfr = p.nframes[b];
-    const int64_t tb = (int64_t)chunk * G::GROUPS;
+    const int tb = chunk * G::GROUPS;  // first frame of the chunk (frames * S fits an int)
     if (tb >= nfr) continue;  // uniform
     const int n = (int)p.lengths[b];
     const float *x = p.sig + p.offsets[b];
@@ -172,16 +177,14 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void stft_wave_kernel(const FastP
     // inside the signal.  Otherwise per-lane bookkeeping: lanes of a frame past the end
     // recompute the last frame (their rows are never stored); frames touching a signal end are
     // gathered with reflected indices (1: one bounce suffices, 2: general reflection).
-    const int start0 = (int)(tb * S) - p.pad_left;
+    const int start0 = tb * S - p.pad_left;
     bool valid = true;
-    int64_t t = tb + g;
     int start = start0 + g * S;
     int wmode = 0;
     if (!(tb + G::GROUPS <= nfr && start0 >= (PRE ? 1 : 0) &&
           start0 + (G::GROUPS - 1) * S + NROWS * N2 <= n)) {
       valid = tb + g < nfr;
-      t = valid ? tb + g : nfr - 1;
-      start = (int)(t * S) - p.pad_left;
+      start = (valid ? tb + g : (int)nfr - 1) * S - p.pad_left;
       int mode = 0;
       if (start < 0 || start + NROWS * N2 > n) mode = 1;
       if (start < -n || start + L > 2 * n) mode = 2;
@@ -420,7 +423,9 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void stft_wave_kernel(const FastP
     wave_sync();
 
     // ---- filter bank: lane (g, r) integrates one filter per slot
-    float *orow = p.out + (p.row_off[b] + t) * p.out_stride;
+    // scalar row base + a 32-bit lane offset: no 64-bit vector arithmetic per store
+    float *obase = p.out + (p.row_off[b] + tb) * p.out_stride;
+    const int lane_off = g * (int)p.out_stride + col0;
     for (int sl = 0; sl < p.ell_slots; ++sl) {
       const int len = p.ell_len[sl];  // bins per row of this slot, multiple of 8
       const int meta = meta_lds[sl * N2 + r];
@@ -447,14 +452,14 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void stft_wave_kernel(const FastP
       if constexpr (PDS_ABLATE & 64) {
         keep_alive(acc);
       } else {
-        if (valid && f >= 0) orow[col0 + f] = acc;
+        if (valid && f >= 0) obase[lane_off + f] = acc;
       }
     }
     if (p.include_energy && r == 0) {
       float e = Pg[NB] * p.inv_L;
       if (!use_power) e = __builtin_amdgcn_sqrtf(e);
       if (p.use_log) e = __logf(p.log_floor > e ? p.log_floor : e);
-      if (valid) orow[0] = e;
+      if (valid) obase[lane_off - col0] = e;
     }
     wave_sync();
   }
@@ -493,7 +498,8 @@ static int32_t launch_wave(const pds_stft_plan *plan, const BatchArgs &a) {
   p.inv_L = 1.0f / (float)plan->d.frame_length;
   p.num_utts = a.B;
   const int64_t chunks = (a.max_frames + G::GROUPS - 1) / G::GROUPS;
-  if (chunks * a.B > 0x7fffffff || chunks > 0x3fffffff) {
+  if (chunks * a.B > 0x7fffffff || chunks > 0x3fffffff || a.out_stride * G::GROUPS > 0x7fffffff ||
+      a.max_frames * plan->d.frame_shift > 0x7fffffff) {
     set_error("stft_batch: too many frame chunks in one call");
     return PDS_ERR_INVALID;
   }
@@ -527,6 +533,9 @@ static int32_t launch_wave(const pds_stft_plan *plan, const BatchArgs &a) {
   int64_t grid = (int64_t)ft.num_cus * wgs_per_cu;
   const int64_t need = (chunks * a.B + WAVES - 1) / WAVES;
   if (grid > need) grid = need;
+  const int64_t grid_waves = grid * WAVES;
+  p.step_utts = (int)(grid_waves / chunks);
+  p.step_chunks = (int)(grid_waves % chunks);
   hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(WAVES * 64), smem, a.stream, p);
   PDS_HIP(hipGetLastError());
   return PDS_OK;

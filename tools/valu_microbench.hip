@@ -63,6 +63,22 @@ __global__ void bench(float *out, int iters) {
       REP8(asm volatile("ds_write_b64 %1, %0\n ds_write_b64 %1, %0 offset:512\n ds_write_b64 %1, %0 offset:1024\n ds_write_b64 %1, %0 offset:1536\n"
                         "ds_write_b64 %1, %0 offset:2048\n ds_write_b64 %1, %0 offset:2560\n ds_write_b64 %1, %0 offset:3072\n ds_write_b64 %1, %0 offset:3584\n s_waitcnt lgkmcnt(0)\n"
                         :: "v"(p0), "v"(addr8) : "memory");)
+    } else if constexpr (KIND == 11) {  // v_add_f32 interleaved 1:1 with independent s_add_u32
+      unsigned sa = i, sb = 3;
+      REP8(asm volatile("v_add_f32 %0, %0, %9\n s_add_u32 %8, %8, %10\n v_add_f32 %1, %1, %9\n s_add_u32 %8, %8, %10\n"
+                        "v_add_f32 %2, %2, %9\n s_add_u32 %8, %8, %10\n v_add_f32 %3, %3, %9\n s_add_u32 %8, %8, %10\n"
+                        "v_add_f32 %4, %4, %9\n s_add_u32 %8, %8, %10\n v_add_f32 %5, %5, %9\n s_add_u32 %8, %8, %10\n"
+                        "v_add_f32 %6, %6, %9\n s_add_u32 %8, %8, %10\n v_add_f32 %7, %7, %9\n s_add_u32 %8, %8, %10\n"
+                        : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7), "+s"(sa) : "v"(b0), "s"(sb) : "scc");)
+      a0 += (float)sa;
+    } else if constexpr (KIND == 12) {  // v_add_f32 interleaved 1:1 with s_nop 0
+      REP8(asm volatile("v_add_f32 %0, %0, %8\n s_nop 0\n v_add_f32 %1, %1, %8\n s_nop 0\n v_add_f32 %2, %2, %8\n s_nop 0\n v_add_f32 %3, %3, %8\n s_nop 0\n"
+                        "v_add_f32 %4, %4, %8\n s_nop 0\n v_add_f32 %5, %5, %8\n s_nop 0\n v_add_f32 %6, %6, %8\n s_nop 0\n v_add_f32 %7, %7, %8\n s_nop 0\n"
+                        : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b0));)
+    } else if constexpr (KIND == 13) {  // v_add_f32 interleaved 1:1 with s_waitcnt (nothing outstanding)
+      REP8(asm volatile("v_add_f32 %0, %0, %8\n s_waitcnt lgkmcnt(0)\n v_add_f32 %1, %1, %8\n s_waitcnt lgkmcnt(0)\n v_add_f32 %2, %2, %8\n s_waitcnt lgkmcnt(0)\n v_add_f32 %3, %3, %8\n s_waitcnt lgkmcnt(0)\n"
+                        "v_add_f32 %4, %4, %8\n s_waitcnt lgkmcnt(0)\n v_add_f32 %5, %5, %8\n s_waitcnt lgkmcnt(0)\n v_add_f32 %6, %6, %8\n s_waitcnt lgkmcnt(0)\n v_add_f32 %7, %7, %8\n s_waitcnt lgkmcnt(0)\n"
+                        : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b0));)
     } else if constexpr (KIND == 10) {  // ds_read_b128 x8
       typedef float float4_ __attribute__((ext_vector_type(4)));
       float4_ r0, r1, r2, r3;
@@ -112,5 +128,9 @@ int main() {
   run<7>("ds_write_b32", 64);
   run<9>("ds_write_b64", 64);
   run<10>("ds_read_b128", 64);
+  // per VALU instruction (64 per iteration) with an equal number of scalar instructions mixed in
+  run<11>("v_add+s_add", 64);
+  run<12>("v_add+s_nop", 64);
+  run<13>("v_add+s_waitcnt", 64);
   return 0;
 }
