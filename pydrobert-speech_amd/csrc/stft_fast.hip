@@ -61,6 +61,7 @@ struct FastParams {
   int L, S, pad_left, include_energy, use_power, use_log;
   float log_floor, inv_L, preemph;
   int chunks_per_utt, num_utts;
+  int waves;  // wavefronts per workgroup of this launch (<= MAXWAVES)
   int step_utts, step_chunks;  // (grid waves) / chunks_per_utt and (grid waves) % chunks_per_utt
 };
 
@@ -109,8 +110,10 @@ struct WaveGeom {
 
 // ELL_LDS: the filter weight rows are staged in LDS (else read from global memory through L1/L2)
 // PRE: pre-emphasis x[i] - c x[i-1] (reference pre.py:146) applied while loading the frame
-template <int N1, int N2, int NROWS, int WAVES, int MINW, bool ELL_LDS, bool PRE>
-__global__ __launch_bounds__(WAVES * 64, MINW) void stft_wave_kernel(const FastParams p) {
+// MAXWAVES / MINW: launch bounds (workgroup size limit, waves per SIMD the register budget must
+// allow); the actual workgroup size is chosen per launch from the LDS the filter table needs
+template <int N1, int N2, int NROWS, int MAXWAVES, int MINW, bool ELL_LDS, bool PRE>
+__global__ __launch_bounds__(MAXWAVES * 64, MINW) void stft_wave_kernel(const FastParams p) {
   using G = WaveGeom<N1, N2, NROWS>;
   constexpr int N = G::N, H1 = G::H1, RS = G::RS, NB = G::NB, PSTR = G::PSTR;
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -123,15 +126,16 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void stft_wave_kernel(const FastP
   // filter table -> LDS once per workgroup (read by every wave, every iteration): per-slot
   // weight rows.  Tables too large for LDS (dense complex banks) stay in global memory and
   // come through L1/L2.
-  float2 *sw_lds = reinterpret_cast<float2 *>(smem + WAVES * (G::EXCH_F2 * 2));  // [N2]
+  const int nthreads = p.waves * 64;
+  float2 *sw_lds = reinterpret_cast<float2 *>(smem + p.waves * (G::EXCH_F2 * 2));  // [N2]
   int *meta_lds = reinterpret_cast<int *>(sw_lds + N2);
   float *ellw_lds = reinterpret_cast<float *>(meta_lds + p.ell_meta_pad);
   if (threadIdx.x < N2) sw_lds[threadIdx.x] = p.tw_special[threadIdx.x];
-  for (int i = threadIdx.x; i < p.ell_slots * N2; i += WAVES * 64) meta_lds[i] = p.ell_meta[i];
+  for (int i = threadIdx.x; i < p.ell_slots * N2; i += nthreads) meta_lds[i] = p.ell_meta[i];
   if constexpr (ELL_LDS)
-    for (int i = threadIdx.x; i < p.ell_wfloats; i += WAVES * 64) ellw_lds[i] = p.ell_w[i];
+    for (int i = threadIdx.x; i < p.ell_wfloats; i += nthreads) ellw_lds[i] = p.ell_w[i];
   // the wave areas start out zeroed so that never-written P padding is finite
-  for (int i = threadIdx.x; i < WAVES * G::EXCH_F2 * 2; i += WAVES * 64) smem[i] = 0.0f;
+  for (int i = threadIdx.x; i < p.waves * G::EXCH_F2 * 2; i += nthreads) smem[i] = 0.0f;
   __syncthreads();
 
 #ifndef PDS_TABLES_PER_ITER
@@ -160,7 +164,7 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void stft_wave_kernel(const FastP
   // chunks) pair -- scalar instructions compete with vector ones for issue slots, so the
   // bookkeeping per item is kept to a handful of them.
   int b = 0;
-  int chunk = blockIdx.x * WAVES + wave;
+  int chunk = blockIdx.x * p.waves + wave;
   while (chunk >= p.chunks_per_utt && b < p.num_utts) {  // once per kernel
     chunk -= p.chunks_per_utt;
     ++b;
@@ -186,7 +190,8 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void stft_wave_kernel(const FastP
       valid = tb + g < nfr;
       start = (valid ? tb + g : (int)nfr - 1) * S - p.pad_left;
       int mode = 0;
-      if (start < 0 || start + NROWS * N2 > n) mode = 1;
+      // (with fused pre-emphasis the direct loads also read x[start - 1])
+      if (start < (PRE ? 1 : 0) || start + NROWS * N2 > n) mode = 1;
       if (start < -n || start + L > 2 * n) mode = 2;
       wmode = __builtin_amdgcn_readfirstlane(__any(mode == 2) ? 2 : (__any(mode == 1) ? 1 : 0));
     }
@@ -467,9 +472,10 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void stft_wave_kernel(const FastP
 
 // ----------------------------------------------------------------------- host side ---
 
-template <int N1, int N2, int NROWS, int WAVES, int MINW>
+template <int N1, int N2, int NROWS, int MINW>
 static int32_t launch_wave(const pds_stft_plan *plan, const BatchArgs &a) {
   using G = WaveGeom<N1, N2, NROWS>;
+  constexpr int CU_WAVES = 4 * MINW;  // resident waves per CU that the register budget allows
   const FastTables &ft = plan->fast;
   FastParams p;
   p.sig = (const float *)a.d_signal;
@@ -504,23 +510,37 @@ static int32_t launch_wave(const pds_stft_plan *plan, const BatchArgs &a) {
     return PDS_ERR_INVALID;
   }
   p.chunks_per_utt = (int)chunks;
-  // LDS: the waves' exchange areas, then the filter table if it leaves room for the target
-  // number of resident workgroups
+  // LDS per workgroup: one exchange area per wave, the small tables, and the filter weight
+  // rows when they fit.  Workgroup shapes in order of preference -- all CU_WAVES resident as two
+  // workgroups, as one workgroup (one copy of the table instead of two), then fewer resident waves
+  // with the table still in LDS (measured on the 38 KB gammatone table at N = 1024: 6 waves with
+  // LDS weights beat 8 waves reading them through L1/L2 by 33 %).  Tables too large even for that
+  // stay in global memory.
   p.ell_meta_pad = (ft.ell_slots * N2 + 3) / 4 * 4;
-  const size_t wave_bytes = (size_t)WAVES * G::EXCH_F2 * 8 + (size_t)N2 * 8 + (size_t)p.ell_meta_pad * 4;
+  const size_t lds_cu = 160 * 1024;
+  const size_t per_wave = (size_t)G::EXCH_F2 * 8;
+  const size_t fixed = (size_t)N2 * 8 + (size_t)p.ell_meta_pad * 4;
   const size_t table_bytes = (size_t)ft.ell_wfloats * 4;
-  const int target_wgs = std::max(1, 4 * MINW / WAVES);
-  const size_t budget = (size_t)(160 * 1024) / target_wgs;
-  const bool in_lds = wave_bytes + table_bytes <= budget;
+  const int shapes[4][2] = {{CU_WAVES / 2, 2}, {CU_WAVES, 1}, {CU_WAVES * 3 / 4, 1}, {CU_WAVES * 5 / 8, 1}};
+  int waves = CU_WAVES / 2, wgs_per_cu = 2;
+  bool in_lds = false;
+  for (const auto &shape : shapes)
+    if (shape[0] * per_wave + fixed + table_bytes <= lds_cu / shape[1]) {
+      waves = shape[0];
+      wgs_per_cu = shape[1];
+      in_lds = true;
+      break;
+    }
   const bool pre = a.preemph != 0.0;
   // the fused pre-emphasis variant exists for LDS-resident tables only; the rare other case
   // (dense complex bank at N >= 1024 plus pre-emphasis) takes the direct-DFT kernel
   if (pre && !in_lds) return launch_stft_generic_f32(plan, a);
   p.preemph = (float)a.preemph;
-  const size_t smem = wave_bytes + (in_lds ? table_bytes : 0);
-  auto kern = pre      ? stft_wave_kernel<N1, N2, NROWS, WAVES, MINW, true, true>
-              : in_lds ? stft_wave_kernel<N1, N2, NROWS, WAVES, MINW, true, false>
-                       : stft_wave_kernel<N1, N2, NROWS, WAVES, MINW, false, false>;
+  p.waves = waves;
+  const size_t smem = waves * per_wave + fixed + (in_lds ? table_bytes : 0);
+  auto kern = pre      ? stft_wave_kernel<N1, N2, NROWS, CU_WAVES, MINW, true, true>
+              : in_lds ? stft_wave_kernel<N1, N2, NROWS, CU_WAVES, MINW, true, false>
+                       : stft_wave_kernel<N1, N2, NROWS, CU_WAVES, MINW, false, false>;
   static size_t attr_smem[3] = {0, 0, 0};  // per instantiation
   const int which = pre ? 2 : (in_lds ? 1 : 0);
   if (smem > attr_smem[which]) {
@@ -528,15 +548,13 @@ static int32_t launch_wave(const pds_stft_plan *plan, const BatchArgs &a) {
                                 (int)smem));
     attr_smem[which] = smem;
   }
-  int wgs_per_cu = (int)((size_t)(160 * 1024) / smem);
-  wgs_per_cu = std::max(1, std::min(wgs_per_cu, target_wgs));
   int64_t grid = (int64_t)ft.num_cus * wgs_per_cu;
-  const int64_t need = (chunks * a.B + WAVES - 1) / WAVES;
+  const int64_t need = (chunks * a.B + waves - 1) / waves;
   if (grid > need) grid = need;
-  const int64_t grid_waves = grid * WAVES;
+  const int64_t grid_waves = grid * waves;
   p.step_utts = (int)(grid_waves / chunks);
   p.step_chunks = (int)(grid_waves % chunks);
-  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(WAVES * 64), smem, a.stream, p);
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(waves * 64), smem, a.stream, p);
   PDS_HIP(hipGetLastError());
   return PDS_OK;
 }
@@ -545,30 +563,30 @@ static int32_t launch_wave(const pds_stft_plan *plan, const BatchArgs &a) {
 // (e.g. 25 ms @ 16 kHz = 400 samples = 25 rows of 16) and round other lengths up.
 //   N = 128 : 16 x 8      N = 256 : 32 x 8      N = 512 : 32 x 16
 //   N = 1024: 64 x 16     N = 2048: 64 x 32
-#define PDS_GEOM_ROWS(N1, N2, R, WAVES, MINW) \
-  if (rows <= R) return launch_wave<N1, N2, R, WAVES, MINW>(plan, a);
+#define PDS_GEOM_ROWS(N1, N2, R, MINW) \
+  if (rows <= R) return launch_wave<N1, N2, R, MINW>(plan, a);
 
 int32_t launch_stft_fast_f32(const pds_stft_plan *plan, const BatchArgs &a) {
   const int rows = plan->fast.rows;
   switch (plan->fast.kind) {
     case 128:
-      PDS_GEOM_ROWS(16, 8, 10, 8, 4) PDS_GEOM_ROWS(16, 8, 13, 8, 4) PDS_GEOM_ROWS(16, 8, 16, 8, 4)
+      PDS_GEOM_ROWS(16, 8, 10, 4) PDS_GEOM_ROWS(16, 8, 13, 4) PDS_GEOM_ROWS(16, 8, 16, 4)
       break;
     case 256:
-      PDS_GEOM_ROWS(32, 8, 20, 8, 4) PDS_GEOM_ROWS(32, 8, 25, 8, 4) PDS_GEOM_ROWS(32, 8, 28, 8, 4)
-      PDS_GEOM_ROWS(32, 8, 32, 8, 4)
+      PDS_GEOM_ROWS(32, 8, 20, 4) PDS_GEOM_ROWS(32, 8, 25, 4) PDS_GEOM_ROWS(32, 8, 28, 4)
+      PDS_GEOM_ROWS(32, 8, 32, 4)
       break;
     case 512:
-      PDS_GEOM_ROWS(32, 16, 20, 8, 4) PDS_GEOM_ROWS(32, 16, 25, 8, 4) PDS_GEOM_ROWS(32, 16, 28, 8, 4)
-      PDS_GEOM_ROWS(32, 16, 30, 8, 4) PDS_GEOM_ROWS(32, 16, 32, 8, 4)
+      PDS_GEOM_ROWS(32, 16, 20, 4) PDS_GEOM_ROWS(32, 16, 25, 4) PDS_GEOM_ROWS(32, 16, 28, 4)
+      PDS_GEOM_ROWS(32, 16, 30, 4) PDS_GEOM_ROWS(32, 16, 32, 4)
       break;
     case 1024:
-      PDS_GEOM_ROWS(64, 16, 40, 4, 2) PDS_GEOM_ROWS(64, 16, 50, 4, 2) PDS_GEOM_ROWS(64, 16, 60, 4, 2)
-      PDS_GEOM_ROWS(64, 16, 64, 4, 2)
+      PDS_GEOM_ROWS(64, 16, 40, 2) PDS_GEOM_ROWS(64, 16, 50, 2)
+      PDS_GEOM_ROWS(64, 16, 60, 2) PDS_GEOM_ROWS(64, 16, 64, 2)
       break;
     case 2048:
-      PDS_GEOM_ROWS(64, 32, 35, 4, 2) PDS_GEOM_ROWS(64, 32, 38, 4, 2) PDS_GEOM_ROWS(64, 32, 48, 4, 2)
-      PDS_GEOM_ROWS(64, 32, 64, 4, 2)
+      PDS_GEOM_ROWS(64, 32, 35, 2) PDS_GEOM_ROWS(64, 32, 38, 2) PDS_GEOM_ROWS(64, 32, 48, 2)
+      PDS_GEOM_ROWS(64, 32, 64, 2)
       break;
     default:
       break;

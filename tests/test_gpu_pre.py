@@ -82,11 +82,17 @@ def test_fused_preemphasis_float64(golden_pre, golden_meta, master_signal):
     assert_features_close(got, golden_pre["preemph/stft/f8"], rtol=1e-9, atol=1e-9)
 
 
-def test_fused_preemphasis_ragged_batch_vs_oracle(golden_meta, golden_tables):
+@pytest.mark.parametrize("cfg_name", [
+    "c2_tri_mel40",            # centered, N = 512 (16 lanes per frame: DPP predecessor)
+    "v_tri_analytic_nolog",    # causal: frame 0 starts at sample 0, which has no predecessor
+    "c5_gammatone64_48k",      # causal, N = 1024, dense table staged in LDS
+    "v_fbank_8k_bartlett",     # kaldi shift, N = 256 (8 lanes per frame: loaded predecessor)
+])
+def test_fused_preemphasis_ragged_batch_vs_oracle(cfg_name, golden_meta, golden_tables):
     from tests.conftest import oracle_params
 
-    comp = build(golden_meta["configs"]["c2_tri_mel40"])
-    p = oracle_params(golden_tables, "c2_tri_mel40")
+    comp = build(golden_meta["configs"][cfg_name])
+    p = oracle_params(golden_tables, cfg_name)
     rng = np.random.default_rng(8)
     L, S = comp.frame_length, comp.frame_shift
     sigs = [(3000 * rng.standard_normal(n)).astype("f4") for n in (L // 2 + 1, 1, 0, 3 * L, 64 * S + 5, 17 * S)]
