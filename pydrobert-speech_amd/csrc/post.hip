@@ -111,6 +111,94 @@ __global__ __launch_bounds__(256) void deltas_rows_kernel(
   }
 }
 
+// ragged rows, register-window form for the reference's delta filters (filter k has 2 k W + 1
+// taps, post.py:441-452): a thread owns 8 consecutive rows of one coefficient, reads the
+// 8 + 2 K W statics it needs once (edge clamping resolved in the row index), converts them to
+// float64 once and produces all 8 x K deltas from registers with the taps held in scalar
+// registers.  No LDS, no barrier: the rows a neighbouring thread re-reads come out of L1/L2, HBM
+// sees each static once.  ~40 instructions per static instead of ~80 for the tiled kernel above,
+// which is what bounds this kernel (28 separately rounded float64 operations per static for
+// K = 2, W = 2).  Filters that do not have the expected lengths take the generic loop at the end.
+#ifndef PDS_DELTA_ROWS
+#define PDS_DELTA_ROWS 8  // consecutive rows per thread
+#endif
+template <int K, int W>
+__global__ __launch_bounds__(256) void deltas_rows_win_kernel(
+    const float *__restrict__ in, int64_t in_stride, const int64_t *__restrict__ row_off,
+    const int64_t *__restrict__ nrows, int inner, const double *__restrict__ filts,
+    const int32_t *__restrict__ filt_off, float *__restrict__ out, int64_t out_stride,
+    int copy_statics) {
+  constexpr int H = K * W, R = PDS_DELTA_ROWS, NV = R + 2 * H;
+  constexpr int TAPS = K * (K + 1) * W + K;  // sum over k of 2 k W + 1
+  const int b = blockIdx.y;
+  const int64_t T = nrows[b];
+  const int64_t items = (T + R - 1) / R * inner;
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if ((int64_t)blockIdx.x * 256 >= items) return;
+  const float *src = in + row_off[b] * in_stride;
+  float *dst = out + row_off[b] * out_stride;
+  bool regular = true;
+#pragma unroll
+  for (int k = 1; k <= K; ++k) regular = regular && filt_off[k] - filt_off[k - 1] == 2 * k * W + 1;
+  if (e >= items) return;
+  const int64_t g = e / inner;
+  const int i = (int)(e - g * inner);
+  const int64_t t0 = g * R;
+  if (regular) {
+    double f[TAPS];
+#pragma unroll
+    for (int j = 0; j < TAPS; ++j) f[j] = filts[filt_off[0] + j];
+    double v[NV];
+    if (t0 >= H && t0 + R + H <= T) {
+      const float *c = src + (t0 - H) * in_stride + i;
+#pragma unroll
+      for (int r = 0; r < NV; ++r) v[r] = (double)c[r * in_stride];
+    } else {
+#pragma unroll
+      for (int r = 0; r < NV; ++r) {
+        int64_t t = t0 - H + r;
+        t = t < 0 ? 0 : (t >= T ? T - 1 : t);  // "edge" padding (post.py:447)
+        v[r] = (double)src[t * in_stride + i];
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      if (t0 + r < T) {
+        float *orow = dst + (t0 + r) * out_stride + i;
+        if (copy_statics) orow[0] = (float)v[H + r];
+        int fo = 0;
+#pragma unroll
+        for (int k = 1; k <= K; ++k) {
+          const int len = 2 * k * W + 1, M = k * W;
+          double acc = 0.0;
+#pragma unroll
+          for (int j = 0; j < len; ++j)
+            acc = __dadd_rn(acc, __dmul_rn(f[fo + j], v[H + r + j - M]));
+          orow[(int64_t)k * inner] = (float)acc;
+          fo += len;
+        }
+      }
+    }
+    return;
+  }
+  for (int r = 0; r < R && t0 + r < T; ++r) {
+    const int64_t t = t0 + r;
+    float *orow = dst + t * out_stride + i;
+    if (copy_statics) orow[0] = src[t * in_stride + i];
+    for (int k = 1; k <= K; ++k) {
+      const int lo = filt_off[k - 1], len = filt_off[k] - lo;
+      const int M = (len - 1) / 2;
+      double acc = 0.0;
+      for (int j = 0; j < len; ++j) {
+        int64_t tt = t + j - M;
+        tt = tt < 0 ? 0 : (tt >= T ? T - 1 : tt);
+        acc = __dadd_rn(acc, __dmul_rn(filts[lo + j], (double)src[tt * in_stride + i]));
+      }
+      orow[(int64_t)k * inner] = (float)acc;
+    }
+  }
+}
+
 // ------------------------------------------------------------------ CMVN -----------
 
 constexpr int kStatSlabs = 128;  // partial-sum slabs over `outer` (deterministic two-stage sum)
@@ -317,13 +405,34 @@ int32_t pds_deltas_rows_f32(const float *d_in, int64_t in_stride, const int64_t 
   if (in_stride < inner || out_stride < (int64_t)(K + 1) * inner)
     return pds::invalid_post("deltas_rows: stride too small");
   if (halo < 0) return pds::invalid_post("deltas_rows: negative halo");
+  // statics already in place when the input IS the output buffer's first columns
+  const int copy_statics = !(d_in == d_out && in_stride == out_stride);
+  if (K >= 1 && halo >= K && halo % K == 0) {
+    // the reference's filter family: register-window kernel (checks the lengths itself)
+    const int W = halo / K;
+    void (*kern)(const float *, int64_t, const int64_t *, const int64_t *, int, const double *,
+                 const int32_t *, float *, int64_t, int) = nullptr;
+#define PDS_DELTA_CASE(KK, WW) \
+  if (K == KK && W == WW) kern = pds::deltas_rows_win_kernel<KK, WW>;
+    PDS_DELTA_CASE(1, 1) PDS_DELTA_CASE(1, 2) PDS_DELTA_CASE(1, 3) PDS_DELTA_CASE(1, 4)
+    PDS_DELTA_CASE(2, 1) PDS_DELTA_CASE(2, 2) PDS_DELTA_CASE(2, 3)
+    PDS_DELTA_CASE(3, 1) PDS_DELTA_CASE(3, 2)
+#undef PDS_DELTA_CASE
+    const int64_t items = (max_rows + PDS_DELTA_ROWS - 1) / PDS_DELTA_ROWS * inner;
+    if (kern && items < ((int64_t)1 << 39)) {
+      dim3 grid((unsigned)((items + 255) / 256), (unsigned)B);
+      hipLaunchKernelGGL(kern, grid, dim3(256), 0, (hipStream_t)stream, d_in, in_stride,
+                         d_row_off, d_nrows, inner, d_filts, d_filt_off, d_out, out_stride,
+                         copy_statics);
+      PDS_HIP(hipGetLastError());
+      return PDS_OK;
+    }
+  }
   int rows_per_block = (24 * 1024 / 4) / inner - 2 * halo;  // ~24 KB of LDS per block
   if (rows_per_block > 64) rows_per_block = 64;
   if (rows_per_block < 1) return pds::invalid_post("deltas_rows: rows too wide for the LDS tile");
   const size_t smem = (size_t)(rows_per_block + 2 * halo) * inner * sizeof(float);
   dim3 grid((unsigned)((max_rows + rows_per_block - 1) / rows_per_block), (unsigned)B);
-  // statics already in place when the input IS the output buffer's first columns
-  const int copy_statics = !(d_in == d_out && in_stride == out_stride);
   hipLaunchKernelGGL(pds::deltas_rows_kernel, grid, dim3(256), smem, (hipStream_t)stream, d_in,
                      in_stride, d_row_off, d_nrows, inner, d_filts, d_filt_off, K, halo, d_out,
                      out_stride, rows_per_block, copy_statics);

@@ -143,6 +143,63 @@ def test_rows_variants_match_per_utterance_apply():
         assert np.allclose(got[rows2[b] : rows2[b + 1]], want, rtol=1e-9, atol=1e-9)
 
 
+@pytest.mark.parametrize("K,W", [(1, 1), (1, 2), (2, 1), (2, 2), (2, 3), (3, 2), (1, 4), (3, 3), (4, 2)])
+def test_rows_deltas_every_filter_family_member_is_exact(K, W):
+    # (3, 3) and (4, 2) have no register-window instantiation and take the LDS-tiled kernel;
+    # float64 accumulation in the oracle's order => identical float32 results
+    import torch
+
+    rng = np.random.default_rng(100 * K + W)
+    lens = [1, 2, 8, 9, 2 * K * W + 1, 8 * 13, 8 * 13 + 1, 333, 7]
+    rows = np.concatenate([[0], np.cumsum(lens)])
+    F = 81
+    feats = (rng.standard_normal((rows[-1], F)) * 3 + 1).astype("f4")
+    d = Deltas(K, context_window=W)
+    got = d.apply_rows(torch.from_numpy(feats).cuda(), rows).cpu().numpy()
+    assert got.shape == (rows[-1], (K + 1) * F)
+    for b in range(len(lens)):
+        want = orc.deltas(feats[rows[b] : rows[b + 1]], axis=0, num_deltas=K, context_window=W, target_axis=1)
+        assert np.array_equal(got[rows[b] : rows[b + 1]], want), (K, W, lens[b])
+
+
+def test_rows_deltas_c_abi_with_filters_outside_the_family():
+    # the C entry point takes any odd-length filters: lengths that do not match 2 k W + 1 run
+    # the kernel's generic loop (K = 2, halo 4 would be W = 2 with lengths 5 and 9)
+    import ctypes
+
+    import torch
+
+    from pydrobert_speech_amd import _native
+
+    lib = _native.lib()
+    rng = np.random.default_rng(77)
+    filts = [rng.standard_normal(3), rng.standard_normal(9)]
+    lens = [5, 1, 40, 17]
+    rows = np.concatenate([[0], np.cumsum(lens)])
+    F = 13
+    feats = rng.standard_normal((rows[-1], F)).astype("f4")
+    d_in = torch.from_numpy(feats).cuda()
+    d_out = torch.full((rows[-1], 3 * F), float("nan"), dtype=torch.float32, device="cuda")
+    d_filts = torch.from_numpy(np.concatenate(filts)).cuda()
+    d_offs = torch.tensor([0, 3, 12], dtype=torch.int32, device="cuda")
+    d_rows = torch.from_numpy(rows[:-1].astype(np.int64)).cuda()
+    d_n = torch.tensor(lens, dtype=torch.int64, device="cuda")
+    rc = lib.pds_deltas_rows_f32(d_in.data_ptr(), F, d_rows.data_ptr(), d_n.data_ptr(), len(lens), max(lens), F,
+                                 d_filts.data_ptr(), d_offs.data_ptr(), 2, 4, d_out.data_ptr(), 3 * F,
+                                 ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+    _native.check(rc, "pds_deltas_rows")
+    got = d_out.cpu().numpy()
+    for b, T in enumerate(lens):
+        x = feats[rows[b] : rows[b + 1]].astype(np.float64)
+        assert np.array_equal(got[rows[b] : rows[b + 1], :F], feats[rows[b] : rows[b + 1]])
+        for k, f in enumerate(filts, 1):
+            M = (len(f) - 1) // 2
+            acc = np.zeros_like(x)
+            for j, w in enumerate(f):
+                acc += w * x[np.clip(np.arange(T) + j - M, 0, T - 1)]
+            assert np.array_equal(got[rows[b] : rows[b + 1], k * F : (k + 1) * F], acc.astype("f4")), (b, k)
+
+
 def test_statics_and_deltas_share_one_buffer():
     # the pipeline layout of BASELINE.json configs[2]: the STFT kernel writes the statics with a
     # row stride that leaves room for the deltas, which are then added in place
