@@ -301,34 +301,56 @@ static int32_t launch_cmvn_apply(const T *d_in, int64_t outer, int64_t C, int64_
   return PDS_OK;
 }
 
-// per-utterance CMVN over ragged rows: one block per (utterance, 64-column chunk);
-// pass 1 statistics, pass 2 normalise (the rows are re-read from L2)
+// per-utterance CMVN over ragged rows: one block per (utterance, 64-column chunk), 16 row
+// phases x 64 columns; pass 1 statistics with 8 independent row loads in flight per thread
+// (a 10 s utterance is only 1000 rows, so the latency of a load is what has to be covered),
+// pass 2 normalises (the rows are re-read from L2)
+constexpr int kRowPhases = 16;
 template <typename OutT>
-__global__ __launch_bounds__(256) void cmvn_rows_kernel(
+__global__ __launch_bounds__(kRowPhases * 64) void cmvn_rows_kernel(
     const float *__restrict__ in, int64_t in_stride, const int64_t *__restrict__ row_off,
     const int64_t *__restrict__ nrows, int C, int norm_var, double *__restrict__ stats,
     OutT *__restrict__ out, int64_t out_stride, int32_t *__restrict__ zero_var) {
-  __shared__ double red[2][4][64];
+  constexpr int P = kRowPhases, U = 8;
+  __shared__ double red[2][P][64];
   __shared__ double sc[64], sh[64];
   const int b = blockIdx.y;
   const int lane = threadIdx.x & 63, phase = threadIdx.x >> 6;
   const int c = blockIdx.x * 64 + lane;
   const int64_t T = nrows[b];
   if (T <= 0) return;
-  const float *src = in + row_off[b] * in_stride;
+  const float *src = in + row_off[b] * in_stride + (c < C ? c : 0);
   double s1 = 0.0, s2 = 0.0;
-  if (c < C)
-    for (int64_t t = phase; t < T; t += 4) {
-      const double v = (double)src[t * in_stride + c];
-      s1 += v;
-      s2 += v * v;
+  if (c < C) {
+    int64_t t = phase;
+    for (; t + (U - 1) * P < T; t += U * P) {
+      float v[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) v[u] = src[(t + u * P) * in_stride];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const double d = (double)v[u];
+        s1 += d;
+        s2 += d * d;
+      }
     }
+    for (; t < T; t += P) {
+      const double d = (double)src[t * in_stride];
+      s1 += d;
+      s2 += d * d;
+    }
+  }
   red[0][phase][lane] = s1;
   red[1][phase][lane] = s2;
   __syncthreads();
   if (phase == 0 && c < C) {
-    s1 = (red[0][0][lane] + red[0][1][lane]) + (red[0][2][lane] + red[0][3][lane]);
-    s2 = (red[1][0][lane] + red[1][1][lane]) + (red[1][2][lane] + red[1][3][lane]);
+    s1 = 0.0;
+    s2 = 0.0;
+#pragma unroll
+    for (int q = 0; q < P; ++q) {  // fixed order: deterministic
+      s1 += red[0][q][lane];
+      s2 += red[1][q][lane];
+    }
     stats[((int64_t)b * 2 + 0) * C + c] = s1;
     stats[((int64_t)b * 2 + 1) * C + c] = s2;
     const double mean = s1 / (double)T;
@@ -346,10 +368,19 @@ __global__ __launch_bounds__(256) void cmvn_rows_kernel(
   }
   __syncthreads();
   if (c < C) {
-    OutT *dst = out + row_off[b] * out_stride;
+    OutT *dst = out + row_off[b] * out_stride + c;
     const double scale = sc[lane], shift = sh[lane];
-    for (int64_t t = phase; t < T; t += 4)
-      dst[t * out_stride + c] = (OutT)__dsub_rn(__dmul_rn((double)src[t * in_stride + c], scale), shift);
+    int64_t t = phase;
+    for (; t + (U - 1) * P < T; t += U * P) {
+      float v[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) v[u] = src[(t + u * P) * in_stride];
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+        dst[(t + u * P) * out_stride] = (OutT)__dsub_rn(__dmul_rn((double)v[u], scale), shift);
+    }
+    for (; t < T; t += P)
+      dst[t * out_stride] = (OutT)__dsub_rn(__dmul_rn((double)src[t * in_stride], scale), shift);
   }
 }
 
@@ -364,8 +395,8 @@ static int32_t launch_cmvn_rows(const float *d_in, int64_t in_stride, const int6
   if (!d_in || !d_row_off || !d_nrows || !d_stats || !d_out)
     return invalid_post("cmvn_rows: null pointer");
   hipLaunchKernelGGL(cmvn_rows_kernel<OutT>, dim3((unsigned)((C + 63) / 64), (unsigned)B),
-                     dim3(256), 0, (hipStream_t)stream, d_in, in_stride, d_row_off, d_nrows, C,
-                     norm_var, d_stats, d_out, out_stride, d_zero_var);
+                     dim3(kRowPhases * 64), 0, (hipStream_t)stream, d_in, in_stride, d_row_off,
+                     d_nrows, C, norm_var, d_stats, d_out, out_stride, d_zero_var);
   PDS_HIP(hipGetLastError());
   return PDS_OK;
 }
