@@ -80,6 +80,19 @@ __device__ __forceinline__ float dpp_row_shr_keep(float old, float src) {
                                                     0x110 + M, 0xf, 0xf, false));
 }
 
+// natural log as v_log_f32 (log2, 1 ulp) times ln 2.  The argument is never below the plan's log
+// floor, which plan creation requires to be a normal float for this kernel, so the denormal
+// rescue sequence of the library logf is dead weight (12 instructions per value).
+__device__ __forceinline__ float fast_log(float x) {
+  return __builtin_amdgcn_logf(x) * 0.69314718055994530942f;
+}
+
+// x + (x of the lane selected by a DPP control word within the row)
+template <int CTRL>
+__device__ __forceinline__ float dpp_add(float x) {
+  return x + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xf, 0xf, false));
+}
+
 __device__ __forceinline__ void wave_sync() {
   // LDS operations of one wave execute in order; this only stops the compiler from moving
   // memory operations across the hand-off between lanes
@@ -112,6 +125,11 @@ struct WaveGeom {
 // PRE: pre-emphasis x[i] - c x[i-1] (reference pre.py:146) applied while loading the frame
 // MAXWAVES / MINW: launch bounds (workgroup size limit, waves per SIMD the register budget must
 // allow); the actual workgroup size is chosen per launch from the LDS the filter table needs
+// filter slots handled by the unrolled slot loop: their row lengths and table offsets arrive with
+// two 16-byte scalar loads per item; banks with more than USLOTS * N2 filters run the remaining
+// slots from memory one by one
+constexpr int USLOTS = 4;
+
 template <int N1, int N2, int NROWS, int MAXWAVES, int MINW, bool ELL_LDS, bool PRE>
 __global__ __launch_bounds__(MAXWAVES * 64, MINW) void stft_wave_kernel(const FastParams p) {
   using G = WaveGeom<N1, N2, NROWS>;
@@ -131,17 +149,15 @@ __global__ __launch_bounds__(MAXWAVES * 64, MINW) void stft_wave_kernel(const Fa
   int *meta_lds = reinterpret_cast<int *>(sw_lds + N2);
   float *ellw_lds = reinterpret_cast<float *>(meta_lds + p.ell_meta_pad);
   if (threadIdx.x < N2) sw_lds[threadIdx.x] = p.tw_special[threadIdx.x];
-  for (int i = threadIdx.x; i < p.ell_slots * N2; i += nthreads) meta_lds[i] = p.ell_meta[i];
+  // (slots beyond the table read as "no filter": the unrolled slot loop fetches USLOTS entries)
+  for (int i = threadIdx.x; i < p.ell_meta_pad; i += nthreads)
+    meta_lds[i] = i < p.ell_slots * N2 ? p.ell_meta[i] : 0;
   if constexpr (ELL_LDS)
     for (int i = threadIdx.x; i < p.ell_wfloats; i += nthreads) ellw_lds[i] = p.ell_w[i];
   // the wave areas start out zeroed so that never-written P padding is finite
   for (int i = threadIdx.x; i < p.waves * G::EXCH_F2 * 2; i += nthreads) smem[i] = 0.0f;
   __syncthreads();
 
-#ifndef PDS_TABLES_PER_ITER
-#define PDS_TABLES_PER_ITER 0
-#endif
-#if !PDS_TABLES_PER_ITER
   // per-lane constants, loop invariant: window slice and inter-stage twiddles
   float win[NROWS];
   float twr[H1], twi[H1];
@@ -153,7 +169,6 @@ __global__ __launch_bounds__(MAXWAVES * 64, MINW) void stft_wave_kernel(const Fa
     twr[k1] = t.x;
     twi[k1] = t.y;
   }
-#endif
   const int L = p.L, S = p.S;
   const bool use_power = p.use_power != 0;
   const int col0 = p.include_energy ? 1 : 0;
@@ -169,14 +184,35 @@ __global__ __launch_bounds__(MAXWAVES * 64, MINW) void stft_wave_kernel(const Fa
     chunk -= p.chunks_per_utt;
     ++b;
   }
-  for (; b < p.num_utts; chunk += p.step_chunks, b += p.step_utts,
-                         b += chunk >= p.chunks_per_utt ? 1 : 0,
-                         chunk -= chunk >= p.chunks_per_utt ? p.chunks_per_utt : 0) {
-    const int64_t nfr = p.nframes[b];
+  // The utterance record of an item (frame count, length, signal offset, output row) is fetched
+  // during the filter phase of the item before: four dependent scalar-load round trips at the
+  // top of every item otherwise.
+  int nfr = 0, n = 0;
+  int64_t sig_off = 0, out_row = 0;
+  if (b < p.num_utts) {
+    nfr = (int)p.nframes[b];  // (the host checked that frame and sample counts fit an int)
+    n = (int)p.lengths[b];
+    sig_off = p.offsets[b];
+    out_row = p.row_off[b];
+  }
+  while (b < p.num_utts) {
+    int nchunk = chunk + p.step_chunks, nb = b + p.step_utts;
+    if (nchunk >= p.chunks_per_utt) {
+      nchunk -= p.chunks_per_utt;
+      ++nb;
+    }
+    const int pb = nb < p.num_utts ? nb : b;  // record to fetch (any valid one past the end)
     const int tb = chunk * G::GROUPS;  // first frame of the chunk (frames * S fits an int)
-    if (tb >= nfr) continue;  // uniform
-    const int n = (int)p.lengths[b];
-    const float *x = p.sig + p.offsets[b];
+    if (tb >= nfr) {  // uniform: utterance shorter than the longest
+      b = nb;
+      chunk = nchunk;
+      nfr = (int)p.nframes[pb];
+      n = (int)p.lengths[pb];
+      sig_off = p.offsets[pb];
+      out_row = p.row_off[pb];
+      continue;
+    }
+    const float *x = p.sig + sig_off;
     // Common case, decided on scalars: all GROUPS frames exist and every row they read lies
     // inside the signal.  Otherwise per-lane bookkeeping: lanes of a frame past the end
     // recompute the last frame (their rows are never stored); frames touching a signal end are
@@ -188,7 +224,7 @@ __global__ __launch_bounds__(MAXWAVES * 64, MINW) void stft_wave_kernel(const Fa
     if (!(tb + G::GROUPS <= nfr && start0 >= (PRE ? 1 : 0) &&
           start0 + (G::GROUPS - 1) * S + NROWS * N2 <= n)) {
       valid = tb + g < nfr;
-      start = (valid ? tb + g : (int)nfr - 1) * S - p.pad_left;
+      start = (valid ? tb + g : nfr - 1) * S - p.pad_left;
       int mode = 0;
       // (with fused pre-emphasis the direct loads also read x[start - 1])
       if (start < (PRE ? 1 : 0) || start + NROWS * N2 > n) mode = 1;
@@ -200,20 +236,6 @@ __global__ __launch_bounds__(MAXWAVES * 64, MINW) void stft_wave_kernel(const Fa
     // re-read from LDS every iteration rather than held in two registers per lane -- the kernel
     // sits exactly at the 128-VGPR occupancy step
     const float2 sw = sw_lds[r];
-#if PDS_TABLES_PER_ITER
-    // window slice and twiddles re-read every iteration (L1-resident 4 KB tables) instead of
-    // living in 55 registers
-    float win[NROWS];
-    float twr[H1], twi[H1];
-#pragma unroll
-    for (int n1 = 0; n1 < NROWS; ++n1) win[n1] = p.win_lane[r * N1 + n1];
-#pragma unroll
-    for (int k1 = 1; k1 < H1; ++k1) {
-      const float2 t = p.tw_lane[r * H1 + k1];
-      twr[k1] = t.x;
-      twi[k1] = t.y;
-    }
-#endif
     float a[N1];
     float energy = 0.0f;
     if (wmode == 0) {
@@ -267,9 +289,15 @@ __global__ __launch_bounds__(MAXWAVES * 64, MINW) void stft_wave_kernel(const Fa
     }
     if (p.include_energy) {
       // compute.py:392-393, on the un-windowed samples of the frame proper
+      // Rows below N1/2 lie inside the frame (this kernel requires L > N/2); the others are
+      // masked against L.  The limit goes through an opaque asm so that the compares are made
+      // here, per item: hoisted out of the loop they would sit in one scalar register pair per
+      // row for the whole kernel.
+      int lim = L - r;
+      asm volatile("" : "+v"(lim));
 #pragma unroll
       for (int n1 = 0; n1 < NROWS; ++n1) {
-        const float v = (n1 * N2 + r < L) ? a[n1] : 0.0f;
+        const float v = (n1 < N1 / 2 || n1 * N2 < lim) ? a[n1] : 0.0f;
         energy = fmaf(v, v, energy);
       }
     }
@@ -420,22 +448,44 @@ __global__ __launch_bounds__(MAXWAVES * 64, MINW) void stft_wave_kernel(const Fa
       const int j = j0 + r;
       Pg[NB + (j < PSTR - NB ? j : PSTR - NB - 1)] = 0.0f;
     }
-    if (p.include_energy) {
-#pragma unroll
-      for (int off = N2 / 2; off >= 1; off >>= 1) energy += __shfl_xor(energy, off, 64);
-      if (r == 0) Pg[NB] = energy;
-    }
-    wave_sync();
-
     // ---- filter bank: lane (g, r) integrates one filter per slot
     // scalar row base + a 32-bit lane offset: no 64-bit vector arithmetic per store
-    float *obase = p.out + (p.row_off[b] + tb) * p.out_stride;
-    const int lane_off = g * (int)p.out_stride + col0;
-    for (int sl = 0; sl < p.ell_slots; ++sl) {
-      const int len = p.ell_len[sl];  // bins per row of this slot, multiple of 8
-      const int meta = meta_lds[sl * N2 + r];
+    float *obase = p.out + (out_row + tb) * p.out_stride;
+    const unsigned lane_off = (unsigned)(g * (int)p.out_stride + col0);
+    if (p.include_energy) {
+      // sum over the frame's lanes with DPP butterflies (lanes 1^, 2^, 7-, 15- within the row);
+      // every lane ends up with the total, lane 0 of the frame stores it (compute.py:392-398)
+      energy = dpp_add<0xB1>(energy);   // quad_perm [1,0,3,2]
+      energy = dpp_add<0x4E>(energy);   // quad_perm [2,3,0,1]
+      energy = dpp_add<0x141>(energy);  // row_half_mirror
+      if constexpr (N2 >= 16) energy = dpp_add<0x140>(energy);  // row_mirror
+      if constexpr (N2 == 32) energy += __shfl_xor(energy, 16, 64);
+      float e = energy * p.inv_L;
+      if (!use_power) e = __builtin_amdgcn_sqrtf(e);
+      if (p.use_log) e = fast_log(p.log_floor > e ? p.log_floor : e);
+      if (valid && r == 0) obase[lane_off - col0] = e;
+    }
+    int metas[USLOTS];  // first bin of the lane's row | (filter + 1) << 16, per slot
+#pragma unroll
+    for (int sl = 0; sl < USLOTS; ++sl) metas[sl] = meta_lds[sl * N2 + r];
+    // row lengths and table offsets of the first USLOTS slots (tables padded to USLOTS entries)
+    const int4 lens4 = *reinterpret_cast<const int4 *>(p.ell_len);
+    const int4 woff4 = *reinterpret_cast<const int4 *>(p.ell_woff);
+    const int slot_len[USLOTS] = {lens4.x, lens4.y, lens4.z, lens4.w};
+    const int slot_woff[USLOTS] = {woff4.x, woff4.y, woff4.z, woff4.w};
+    static_assert(USLOTS == 4, "slot tables are fetched as one int4 each");
+    wave_sync();
+    // this item's record is dead from here on: fetch the next one under the filter phase
+    b = nb;
+    chunk = nchunk;
+    nfr = (int)p.nframes[pb];
+    n = (int)p.lengths[pb];
+    sig_off = p.offsets[pb];
+    out_row = p.row_off[pb];
+
+    auto run_slot = [&](const int meta, const int len, const int slot_woff_) {
       const float4 *prow = reinterpret_cast<const float4 *>(Pg + (meta & 0xffff));
-      const int woff = p.ell_woff[sl] + r * (len + 4);  // + 4: conflict-free row skew
+      const int woff = slot_woff_ + r * (len + 4);  // + 4: conflict-free row skew
       float acc0 = 0.0f, acc1 = 0.0f, acc2 = 0.0f, acc3 = 0.0f;
       const float4 *wrow = reinterpret_cast<const float4 *>((ELL_LDS ? ellw_lds : p.ell_w) + woff);
       for (int t4 = 0; t4 < ((PDS_ABLATE & 32) ? 2 : len / 4); t4 += 2) {
@@ -452,20 +502,21 @@ __global__ __launch_bounds__(MAXWAVES * 64, MINW) void stft_wave_kernel(const Fa
       }
       float acc = (acc0 + acc1) + (acc2 + acc3);
       // max(val, floor) as Python evaluates it: a NaN stays a NaN (compute.py:459)
-      if (p.use_log) acc = __logf(p.log_floor > acc ? p.log_floor : acc);
-      const int f = (meta >> 16) - 1;
+      if (p.use_log) acc = fast_log(p.log_floor > acc ? p.log_floor : acc);
       if constexpr (PDS_ABLATE & 64) {
         keep_alive(acc);
       } else {
-        if (valid && f >= 0) obase[lane_off + f] = acc;
+        // filter index f = (meta >> 16) - 1; lanes without a filter in this slot have meta < 2^16
+        const unsigned byte_off = (lane_off + (unsigned)(meta >> 16) - 1u) * 4u;
+        if (valid && meta >= 0x10000)
+          *reinterpret_cast<float *>(reinterpret_cast<char *>(obase) + byte_off) = acc;
       }
-    }
-    if (p.include_energy && r == 0) {
-      float e = Pg[NB] * p.inv_L;
-      if (!use_power) e = __builtin_amdgcn_sqrtf(e);
-      if (p.use_log) e = __logf(p.log_floor > e ? p.log_floor : e);
-      if (valid) obase[lane_off - col0] = e;
-    }
+    };
+#pragma unroll
+    for (int sl = 0; sl < USLOTS; ++sl)
+      if (sl < p.ell_slots) run_slot(metas[sl], slot_len[sl], slot_woff[sl]);
+    for (int sl = USLOTS; sl < p.ell_slots; ++sl)
+      run_slot(meta_lds[sl * N2 + r], p.ell_len[sl], p.ell_woff[sl]);
     wave_sync();
   }
 }
@@ -504,7 +555,7 @@ static int32_t launch_wave(const pds_stft_plan *plan, const BatchArgs &a) {
   p.inv_L = 1.0f / (float)plan->d.frame_length;
   p.num_utts = a.B;
   const int64_t chunks = (a.max_frames + G::GROUPS - 1) / G::GROUPS;
-  if (chunks * a.B > 0x7fffffff || chunks > 0x3fffffff || a.out_stride * G::GROUPS > 0x7fffffff ||
+  if (chunks * a.B > 0x7fffffff || chunks > 0x3fffffff || a.out_stride * G::GROUPS > 0x1fffffff ||
       a.max_frames * plan->d.frame_shift > 0x7fffffff) {
     set_error("stft_batch: too many frame chunks in one call");
     return PDS_ERR_INVALID;
@@ -516,7 +567,7 @@ static int32_t launch_wave(const pds_stft_plan *plan, const BatchArgs &a) {
   // with the table still in LDS (measured on the 38 KB gammatone table at N = 1024: 6 waves with
   // LDS weights beat 8 waves reading them through L1/L2 by 33 %).  Tables too large even for that
   // stay in global memory.
-  p.ell_meta_pad = (ft.ell_slots * N2 + 3) / 4 * 4;
+  p.ell_meta_pad = (std::max(ft.ell_slots, USLOTS) * N2 + 3) / 4 * 4;
   const size_t lds_cu = 160 * 1024;
   const size_t per_wave = (size_t)G::EXCH_F2 * 8;
   const size_t fixed = (size_t)N2 * 8 + (size_t)p.ell_meta_pad * 4;
@@ -613,6 +664,8 @@ int32_t fast_tables_create(pds_stft_plan *plan, const double *window, const int3
   const char *off = std::getenv("PDS_STFT_GENERIC");
   if (off && off[0] == '1') return PDS_OK;
   if (d.frame_length > d.dft_size || d.frame_length <= d.dft_size / 2) return PDS_OK;
+  // fast_log() skips the denormal rescue: a floor below the normal range stays on the generic path
+  if (d.use_log && !((float)d.log_floor >= 1.17549435e-38f)) return PDS_OK;
   if (d.num_filts > 32767) return PDS_OK;
   const int N = d.dft_size, H1 = n1 / 2;
   std::vector<float> win((size_t)n1 * n2, 0.0f);
@@ -640,8 +693,8 @@ int32_t fast_tables_create(pds_stft_plan *plan, const double *window, const int3
   // common length (a multiple of 8); zero weights fill the rest.
   const int slots = (d.num_filts + n2 - 1) / n2;
   const int pstr = ((N / 2 + 2 + 15) / 32) * 32 + 16;  // WaveGeom::PSTR
-  std::vector<int32_t> ell_meta((size_t)std::max(slots, 1) * n2, 0), ell_len(std::max(slots, 1), 0),
-      ell_woff(std::max(slots, 1), 0);
+  std::vector<int32_t> ell_meta((size_t)std::max(slots, 1) * n2, 0), ell_len(std::max(slots, USLOTS), 0),
+      ell_woff(std::max(slots, USLOTS), 0);
   std::vector<float> ell_w;
   for (int sl = 0; sl < slots; ++sl) {
     int longest = 8;
