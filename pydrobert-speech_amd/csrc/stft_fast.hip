@@ -705,6 +705,35 @@ int32_t fast_tables_create(pds_stft_plan *plan, const double *window, const int3
       first[j] = col[row_ptr[f]] & ~3;  // cols ascend within a row
       longest = std::max(longest, (span(f) + 7) / 8 * 8);
     }
+    // LDS bank spreading: the lanes of a frame read 16 bytes each from their row's current
+    // position, all at the same step, so rows whose starts coincide modulo 64 banks (16 groups of
+    // 4 bins) collide at every step.  A row may start up to (longest - span) bins early at no
+    // cost (the slack is zero weights): take the early start that collides with the fewest rows
+    // placed so far, rows with the least slack first.  (Identical starts are one broadcast read.)
+    {
+      std::vector<int> lanes;
+      for (int j = 0; j < n2 && sl * n2 + j < d.num_filts; ++j)
+        if (span(order[sl * n2 + j]) > 0) lanes.push_back(j);
+      std::stable_sort(lanes.begin(), lanes.end(), [&](int x, int y) {
+        return span(order[sl * n2 + x]) > span(order[sl * n2 + y]);
+      });
+      std::vector<std::vector<int>> taken(16);
+      for (int j : lanes) {
+        const int slack = std::min((longest - span(order[sl * n2 + j])) / 4, first[j] / 4);
+        int best_shift = 0, best_cost = 1 << 30;
+        for (int sh = 0; sh <= slack; ++sh) {
+          const int q = first[j] / 4 - sh;
+          int cost = 0;
+          for (int other : taken[q % 16]) cost += other != q;
+          if (cost < best_cost) {
+            best_cost = cost;
+            best_shift = sh;
+          }
+        }
+        first[j] -= 4 * best_shift;
+        taken[(first[j] / 4) % 16].push_back(first[j] / 4);
+      }
+    }
     ell_len[sl] = longest;
     ell_woff[sl] = (int32_t)ell_w.size();
     const int wstride = longest + 4;
