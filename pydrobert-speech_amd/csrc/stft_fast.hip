@@ -87,6 +87,16 @@ __device__ __forceinline__ float fast_log(float x) {
   return __builtin_amdgcn_logf(x) * 0.69314718055994530942f;
 }
 
+// Load through the constant address space: tables and utterance records are never written by
+// this kernel, and a uniform address then always becomes a scalar load (the compiler otherwise
+// falls back to 64-lane vector loads wherever it cannot prove that no store precedes the load).
+typedef int Int4 __attribute__((ext_vector_type(4)));
+template <typename T>
+__device__ __forceinline__ T load_const(const T *ptr) {
+  typedef const T __attribute__((address_space(4))) *const_ptr;
+  return *(const_ptr)(uintptr_t)ptr;
+}
+
 // x + (x of the lane selected by a DPP control word within the row)
 template <int CTRL>
 __device__ __forceinline__ float dpp_add(float x) {
@@ -190,10 +200,10 @@ __global__ __launch_bounds__(MAXWAVES * 64, MINW) void stft_wave_kernel(const Fa
   int nfr = 0, n = 0;
   int64_t sig_off = 0, out_row = 0;
   if (b < p.num_utts) {
-    nfr = (int)p.nframes[b];  // (the host checked that frame and sample counts fit an int)
-    n = (int)p.lengths[b];
-    sig_off = p.offsets[b];
-    out_row = p.row_off[b];
+    nfr = (int)load_const(p.nframes + b);  // (frame and sample counts fit an int: host check)
+    n = (int)load_const(p.lengths + b);
+    sig_off = load_const(p.offsets + b);
+    out_row = load_const(p.row_off + b);
   }
   while (b < p.num_utts) {
     int nchunk = chunk + p.step_chunks, nb = b + p.step_utts;
@@ -206,10 +216,10 @@ __global__ __launch_bounds__(MAXWAVES * 64, MINW) void stft_wave_kernel(const Fa
     if (tb >= nfr) {  // uniform: utterance shorter than the longest
       b = nb;
       chunk = nchunk;
-      nfr = (int)p.nframes[pb];
-      n = (int)p.lengths[pb];
-      sig_off = p.offsets[pb];
-      out_row = p.row_off[pb];
+      nfr = (int)load_const(p.nframes + pb);
+      n = (int)load_const(p.lengths + pb);
+      sig_off = load_const(p.offsets + pb);
+      out_row = load_const(p.row_off + pb);
       continue;
     }
     const float *x = p.sig + sig_off;
@@ -416,6 +426,15 @@ __global__ __launch_bounds__(MAXWAVES * 64, MINW) void stft_wave_kernel(const Fa
       sp0 = __builtin_amdgcn_sqrtf(sp0);
       sp1 = __builtin_amdgcn_sqrtf(sp1);
     }
+    // row lengths and table offsets of the first USLOTS slots (tables padded to USLOTS entries):
+    // fetched here so that the P stores below cover the latency.  (Scalar loads return out of
+    // order, so a wait for one is a wait for all: they are issued in two batches per item, this
+    // one and the next item's record at the start of the filter phase.)
+    const Int4 lens4 = load_const(reinterpret_cast<const Int4 *>(p.ell_len));
+    const Int4 woff4 = load_const(reinterpret_cast<const Int4 *>(p.ell_woff));
+    const int slot_len[USLOTS] = {lens4.x, lens4.y, lens4.z, lens4.w};
+    const int slot_woff[USLOTS] = {woff4.x, woff4.y, woff4.z, woff4.w};
+    static_assert(USLOTS == 4, "slot tables are fetched as one int4 each");
     // every lane is done with the exchange area (same wave, in order): reuse it as P
     wave_sync();
     // Stores below avoid lane predicates (each costs exec-mask bookkeeping on the scalar unit):
@@ -468,20 +487,14 @@ __global__ __launch_bounds__(MAXWAVES * 64, MINW) void stft_wave_kernel(const Fa
     int metas[USLOTS];  // first bin of the lane's row | (filter + 1) << 16, per slot
 #pragma unroll
     for (int sl = 0; sl < USLOTS; ++sl) metas[sl] = meta_lds[sl * N2 + r];
-    // row lengths and table offsets of the first USLOTS slots (tables padded to USLOTS entries)
-    const int4 lens4 = *reinterpret_cast<const int4 *>(p.ell_len);
-    const int4 woff4 = *reinterpret_cast<const int4 *>(p.ell_woff);
-    const int slot_len[USLOTS] = {lens4.x, lens4.y, lens4.z, lens4.w};
-    const int slot_woff[USLOTS] = {woff4.x, woff4.y, woff4.z, woff4.w};
-    static_assert(USLOTS == 4, "slot tables are fetched as one int4 each");
     wave_sync();
     // this item's record is dead from here on: fetch the next one under the filter phase
     b = nb;
     chunk = nchunk;
-    nfr = (int)p.nframes[pb];
-    n = (int)p.lengths[pb];
-    sig_off = p.offsets[pb];
-    out_row = p.row_off[pb];
+    nfr = (int)load_const(p.nframes + pb);
+    n = (int)load_const(p.lengths + pb);
+    sig_off = load_const(p.offsets + pb);
+    out_row = load_const(p.row_off + pb);
 
     auto run_slot = [&](const int meta, const int len, const int slot_woff_) {
       const float4 *prow = reinterpret_cast<const float4 *>(Pg + (meta & 0xffff));
@@ -516,7 +529,7 @@ __global__ __launch_bounds__(MAXWAVES * 64, MINW) void stft_wave_kernel(const Fa
     for (int sl = 0; sl < USLOTS; ++sl)
       if (sl < p.ell_slots) run_slot(metas[sl], slot_len[sl], slot_woff[sl]);
     for (int sl = USLOTS; sl < p.ell_slots; ++sl)
-      run_slot(meta_lds[sl * N2 + r], p.ell_len[sl], p.ell_woff[sl]);
+      run_slot(meta_lds[sl * N2 + r], load_const(p.ell_len + sl), load_const(p.ell_woff + sl));
     wave_sync();
   }
 }
