@@ -175,6 +175,16 @@ int32_t pds_deltas_rows_f32(const float *d_in, int64_t in_stride, const int64_t 
                             int32_t K, int32_t halo, float *d_out, int64_t out_stride,
                             void *stream);
 
+/* Stack (reference post.py:494-563) on a packed ragged batch: output row t' of utterance b is
+ * its input rows t' * num_vectors .. t' * num_vectors + num_vectors - 1 side by side, written at
+ * row d_out_row_off[b] + t' of d_out.  pad_mode 0 drops the incomplete last group (the
+ * reference's default), 1 completes it with zeros (numpy.pad "constant"), 2 repeats the last
+ * row ("edge").  max_out_rows bounds the output rows of any one utterance. */
+int32_t pds_stack_rows_f32(const float *d_in, int64_t in_stride, const int64_t *d_row_off,
+                           const int64_t *d_nrows, const int64_t *d_out_row_off, int32_t B,
+                           int64_t max_out_rows, int32_t coeff, int32_t num_vectors,
+                           int32_t pad_mode, float *d_out, int64_t out_stride, void *stream);
+
 /* ---------------------------------------------------------------------------------
  * Standardize / CMVN (reference post.py:193-212 accumulate, 250-295 apply) on a tensor
  * viewed as [outer, coeff, inner]; statistics are over outer x inner per coefficient.

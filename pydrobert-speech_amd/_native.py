@@ -92,6 +92,11 @@ SIGNATURES = {
         [c_void_p, c_int64, c_void_p, c_void_p, c_int32, c_int64, c_int32, c_void_p,
          c_void_p, c_int32, c_int32, c_void_p, c_int64, c_void_p],
     ),
+    "pds_stack_rows_f32": (
+        c_int32,
+        [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int32, c_int64, c_int32, c_int32,
+         c_int32, c_void_p, c_int64, c_void_p],
+    ),
     "pds_cmvn_scratch_len": (c_int64, [c_int64, c_int64]),
     "pds_cmvn_stats_f32": (c_int32, [c_void_p, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_void_p]),
     "pds_cmvn_stats_f64": (c_int32, [c_void_p, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_void_p]),

@@ -199,6 +199,34 @@ __global__ __launch_bounds__(256) void deltas_rows_win_kernel(
   }
 }
 
+// ------------------------------------------------------------------ Stack ----------
+
+// Stack (reference post.py:494-563) over a packed ragged batch: output row t' of utterance b is
+// the concatenation of its input rows t' nv .. t' nv + nv - 1.  Rows past the end of the
+// utterance (only with padding: pad 1 = zeros, 2 = repeat the last row) are synthesised.
+// Pure data movement: one thread per output element, reads and writes coalesced along a row.
+__global__ __launch_bounds__(256) void stack_rows_kernel(
+    const float *__restrict__ in, int64_t in_stride, const int64_t *__restrict__ row_off,
+    const int64_t *__restrict__ nrows, const int64_t *__restrict__ out_row_off, int F, int nv,
+    int pad, float *__restrict__ out, int64_t out_stride) {
+  const int b = blockIdx.y;
+  const int64_t T = nrows[b];
+  const int64_t Tout = pad ? (T + nv - 1) / nv : T / nv;
+  const int64_t width = (int64_t)nv * F;
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= Tout * width) return;
+  const int64_t to = e / width;
+  const int c = (int)(e - to * width);
+  const int v = c / F, i = c - v * F;
+  int64_t t = to * nv + v;
+  float val = 0.0f;
+  if (t < T || pad == 2) {
+    if (t >= T) t = T - 1;
+    val = in[(row_off[b] + t) * in_stride + i];
+  }
+  out[(out_row_off[b] + to) * out_stride + c] = val;
+}
+
 // ------------------------------------------------------------------ CMVN -----------
 
 constexpr int kStatSlabs = 128;  // partial-sum slabs over `outer` (deterministic two-stage sum)
@@ -467,6 +495,27 @@ int32_t pds_deltas_rows_f32(const float *d_in, int64_t in_stride, const int64_t 
   hipLaunchKernelGGL(pds::deltas_rows_kernel, grid, dim3(256), smem, (hipStream_t)stream, d_in,
                      in_stride, d_row_off, d_nrows, inner, d_filts, d_filt_off, K, halo, d_out,
                      out_stride, rows_per_block, copy_statics);
+  PDS_HIP(hipGetLastError());
+  return PDS_OK;
+}
+
+int32_t pds_stack_rows_f32(const float *d_in, int64_t in_stride, const int64_t *d_row_off,
+                          const int64_t *d_nrows, const int64_t *d_out_row_off, int32_t B,
+                          int64_t max_out_rows, int32_t coeff, int32_t num_vectors,
+                          int32_t pad_mode, float *d_out, int64_t out_stride, void *stream) {
+  if (B < 0 || max_out_rows < 0 || coeff <= 0 || num_vectors < 1 || pad_mode < 0 || pad_mode > 2)
+    return pds::invalid_post("stack_rows: bad size or pad mode");
+  if (B == 0 || max_out_rows == 0) return PDS_OK;
+  if (B > 65535) return pds::invalid_post("stack_rows: B > 65535");
+  if (!d_in || !d_row_off || !d_nrows || !d_out_row_off || !d_out)
+    return pds::invalid_post("stack_rows: null pointer");
+  if (in_stride < coeff || out_stride < (int64_t)coeff * num_vectors)
+    return pds::invalid_post("stack_rows: stride too small");
+  const int64_t items = max_out_rows * coeff * num_vectors;
+  dim3 grid((unsigned)((items + 255) / 256), (unsigned)B);
+  hipLaunchKernelGGL(pds::stack_rows_kernel, grid, dim3(256), 0, (hipStream_t)stream, d_in,
+                     in_stride, d_row_off, d_nrows, d_out_row_off, coeff, num_vectors, pad_mode,
+                     d_out, out_stride);
   PDS_HIP(hipGetLastError());
   return PDS_OK;
 }

@@ -5,8 +5,9 @@ the element-wise and stencil arithmetic runs in HIP kernels (``csrc/post.hip``) 
 is no CPU path.  Host code only decides shapes, pads for the non-default ``pad_mode`` s,
 and finalises the ``O(num_coeffs)`` mean/scale vectors of CMVN.
 
-``Stack`` and CMVN statistics files (``rfilename``, ``save``) are outside the hot-path
-scope and are not provided.
+``Stack`` moves data only: views for a single tensor, one copy
+kernel for a packed ragged batch.  CMVN statistics files (``rfilename``, ``save``) go through
+``util.read_signal`` / numpy.
 """
 import abc
 import warnings
@@ -17,7 +18,7 @@ import numpy as np
 from . import _native
 from .alias import AliasedFactory
 
-__all__ = ["CMVN", "Deltas", "PostProcessor", "Standardize"]
+__all__ = ["CMVN", "Deltas", "PostProcessor", "Stack", "Standardize"]
 
 
 class PostProcessor(AliasedFactory):
@@ -76,15 +77,88 @@ class Standardize(PostProcessor):
     aliases = {"standardize", "normalize", "unit", "cmvn"}
 
     def __init__(self, rfilename: Optional[str] = None, norm_var: bool = True, **kwargs):
-        if rfilename is not None:
-            raise NotImplementedError(
-                "loading CMVN statistics from a file is outside this package's scope "
-                "(reference post.py:105-122); accumulate() them instead"
-            )
-        if kwargs:
-            raise TypeError("Invalid keyword arguments: {}".format(tuple(kwargs)))
         self._stats = None  # float64 [2, C + 1]: sums | count, sums of squares | unused
         self._norm_var = bool(norm_var)
+        if rfilename is None:
+            if kwargs:
+                raise TypeError("Invalid keyword arguments: {}".format(tuple(kwargs)))
+            return
+        # Statistics written by save() or by Kaldi's compute-cmvn-stats (reference
+        # post.py:104-122): read with util.read_signal; keyword arguments go to the reader.
+        from .util import read_signal
+
+        if "dtype" in kwargs:
+            self._stats = read_signal(rfilename, **kwargs)
+            return
+        for guess in (np.float64, np.float32, "dm", "fm"):
+            try:
+                self._stats = read_signal(rfilename, dtype=guess, **kwargs)
+                break
+            except (IOError, ValueError, ImportError, TypeError):
+                continue
+        if self._stats is None:
+            raise IOError("Unable to load stats from {}".format(rfilename))
+        if self._stats.ndim == 1:
+            self._stats = self._two_rows(self._stats)
+
+    @staticmethod
+    def _two_rows(flat):
+        """Raw binary statistics -> ``[2, C + 1]`` float64 (reference post.py:124-152)
+
+        A headerless file does not say whether it holds float64 or float32 words.  A valid
+        table has an integral count in ``[0, -1]`` and no negative entry; if the first
+        interpretation fails that test the same bytes are tried as the other float width.
+        """
+
+        def plausible(table):
+            return bool(np.isclose(np.round(table[0, -1]), table[0, -1]) and np.all(table >= 0))
+
+        if flat.dtype not in (np.float32, np.float64):
+            raise ValueError(
+                "Statistics were loaded with a weird data type ({}) and are invalid. Make sure "
+                "the arguments you passed to the init are correct".format(flat.dtype)
+            )
+        other = np.float32 if flat.dtype == np.float64 else np.float64
+        for words in (flat, np.frombuffer(flat.tobytes(), dtype=other).astype(np.float64)):
+            if words.size and words.size % 2 == 0:
+                table = words.reshape(2, -1)
+                if plausible(table):
+                    return table
+        raise IOError(
+            "Could not properly load statistics. Try specifying additional parameters in init "
+            "(see docstring)"
+        )
+
+    def save(self, wfilename: str, key: Optional[str] = None, compress: bool = False,
+             overwrite: bool = True) -> None:
+        """Write the accumulated statistics (reference post.py:307-361)
+
+        ``.npy``: :func:`numpy.save`.  ``.npz``: an archive entry named `key` (default: the first
+        free ``arr_<n>``), next to the archive's existing entries when `overwrite` is true (the
+        reference's flag reads that way round, post.py:349-353), compressed on request.  Any
+        other name: raw float64 words (:meth:`numpy.ndarray.tofile`).
+        """
+        if not self.have_stats:
+            raise ValueError("No stats have been accumulated to save")
+        if wfilename.endswith(".npy"):
+            np.save(wfilename, self._stats)
+        elif wfilename.endswith(".npz"):
+            entries = {}
+            if overwrite:
+                try:
+                    with np.load(wfilename) as archive:
+                        entries = {name: archive[name] for name in archive.files}
+                except IOError:
+                    pass
+            if key is None:
+                n = 0
+                while "arr_{}".format(n) in entries:
+                    n += 1
+                key = "arr_{}".format(n)
+            entries[key] = self._stats
+            (np.savez_compressed if compress else np.savez)(wfilename, **entries)
+        else:
+            self._stats.tofile(wfilename)
 
     @property
     def have_stats(self) -> bool:
@@ -418,3 +492,123 @@ class Deltas(PostProcessor):
                 )
                 _native.check(rc, "pds_deltas_rows")
         return out
+
+
+# ------------------------------------------------------------------ Stack ------------
+
+
+class Stack(PostProcessor):
+    """Concatenate every `num_vectors` consecutive frames into one (reference post.py:494-563)
+
+    `time_axis` is the axis frames are drawn from; `axis` of :func:`apply` the coefficient axis
+    that grows `num_vectors`-fold.  Frames that do not fill a last group are dropped, or, with
+    `pad_mode` (and keyword arguments of :func:`numpy.pad`), the time axis is first padded on
+    the right up to a multiple of `num_vectors`.
+
+    Stacking is data movement, not arithmetic: a host array is re-viewed / re-gathered with
+    numpy and a GPU tensor with torch indexing, exactly as the reference does it, and a packed
+    ragged batch goes through one HIP copy kernel (:func:`apply_rows`).
+    """
+
+    aliases = {"stack"}
+
+    def __init__(self, num_vectors: int, time_axis: int = 0,
+                 pad_mode: Optional[Union[str, Callable]] = None, **kwargs):
+        if num_vectors < 1:
+            raise ValueError(f"Expected num_vectors to be positive, got {num_vectors}")
+        self.num_vectors = num_vectors
+        self.time_axis = time_axis
+        self._pad_mode = pad_mode
+        self._pad_kwargs = kwargs
+
+    def apply(self, features, axis: int = -1, in_place: bool = False):
+        nd = features.ndim if not _is_gpu_tensor(features) else features.dim()
+        axis, time_axis = axis % nd, self.time_axis % nd
+        if axis == time_axis:
+            raise RuntimeError(f"feature and time axes are the same ({axis})")
+        nv = self.num_vectors
+        on_gpu = _is_gpu_tensor(features)
+        T = features.shape[time_axis]
+        if self._pad_mode is not None and T % nv:
+            extra = nv - T % nv
+            if on_gpu:
+                features = self._pad_tensor(features, time_axis, extra)
+            else:
+                widths = [(0, 0)] * nd
+                widths[time_axis] = (0, extra)
+                features = np.pad(features, widths, self._pad_mode, **self._pad_kwargs)
+            in_place = True  # already a private copy
+            T += extra
+        groups = T // nv
+        if nd == 2:
+            # the (T, F) matrix re-read as (T / nv, nv F): a reshape of the time-major layout
+            if not in_place:
+                features = features.clone() if on_gpu else features.copy()
+            mat = features.T if time_axis else features
+            mat = mat[: groups * nv].reshape(groups, mat.shape[1] * nv)
+            return mat.T if time_axis else mat
+        # general rank: frame v of every group, for v = 0 .. nv - 1, side by side on `axis`
+        index = [slice(None)] * nd
+        parts = []
+        for v in range(nv):
+            index[time_axis] = slice(v, groups * nv, nv)
+            parts.append(features[tuple(index)])
+        if on_gpu:
+            return _native.require_device().cat(parts, axis)
+        return np.concatenate(parts, axis)
+
+    def _pad_tensor(self, t, time_axis, extra):
+        torch = _native.require_device()
+        if self._pad_mode == "edge" and not self._pad_kwargs:
+            last = t.narrow(time_axis, t.shape[time_axis] - 1, 1)
+            reps = [1] * t.dim()
+            reps[time_axis] = extra
+            return torch.cat([t, last.repeat(*reps)], time_axis)
+        if self._pad_mode == "constant" and set(self._pad_kwargs) <= {"constant_values"}:
+            shape = list(t.shape)
+            shape[time_axis] = extra
+            fill = self._pad_kwargs.get("constant_values", 0)
+            return torch.cat([t, torch.full(shape, fill, dtype=t.dtype, device=t.device)], time_axis)
+        raise ValueError("GPU tensors support pad_mode 'edge' and 'constant' only")
+
+    def apply_rows(self, feats, row_offsets):
+        """Stack every utterance of a packed ragged batch on the GPU
+
+        `feats`: ``(total_rows, F)`` float32 GPU tensor, utterance b in rows
+        ``row_offsets[b]:row_offsets[b+1]`` (time is the row axis).  Returns
+        ``(stacked, new_row_offsets)`` with ``stacked`` of shape ``(new_total, num_vectors F)``.
+        """
+        torch = _native.require_device()
+        lib = _native.lib()
+        if not _is_gpu_tensor(feats) or feats.dtype != torch.float32 or feats.dim() != 2:
+            raise ValueError("feats must be a 2-D float32 GPU tensor")
+        if self._pad_mode is None:
+            pad = 0
+        elif self._pad_mode == "constant" and not self._pad_kwargs:
+            pad = 1
+        elif self._pad_mode == "edge" and not self._pad_kwargs:
+            pad = 2
+        else:
+            raise ValueError("apply_rows supports pad_mode None, 'constant' (zeros) and 'edge'")
+        if feats.stride(1) != 1:
+            feats = feats.contiguous()
+        nv, F = self.num_vectors, feats.shape[1]
+        rows = np.ascontiguousarray(row_offsets, dtype=np.int64)
+        nrows = np.diff(rows)
+        out_rows = (nrows + nv - 1) // nv if pad else nrows // nv
+        new_offsets = np.concatenate([[0], np.cumsum(out_rows)]).astype(np.int64)
+        out = torch.empty((int(new_offsets[-1]), nv * F), dtype=torch.float32, device=feats.device)
+        B = len(nrows)
+        if B == 0 or out.shape[0] == 0:
+            return out, new_offsets
+        meta = torch.from_numpy(np.stack([rows[:-1], nrows, new_offsets[:-1]])).to(feats.device)
+        with torch.cuda.device(feats.device):
+            for lo in range(0, B, 65535):
+                hi = min(B, lo + 65535)
+                rc = lib.pds_stack_rows_f32(
+                    feats.data_ptr(), feats.stride(0), meta[0, lo:].data_ptr(), meta[1, lo:].data_ptr(),
+                    meta[2, lo:].data_ptr(), hi - lo, int(out_rows[lo:hi].max()), F, nv, pad,
+                    out.data_ptr(), out.stride(0), _stream(torch, feats),
+                )
+                _native.check(rc, "pds_stack_rows")
+        return out, new_offsets

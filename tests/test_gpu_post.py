@@ -260,3 +260,77 @@ def test_hip_graph_capture_of_the_batch_launch():
     graph.replay()
     torch.cuda.synchronize()
     assert torch.allclose(out, eager + 2 * np.log(2.0), atol=2e-4)
+
+
+# ---- section 8(f): statistics files and Stack ---------------------------------------------
+
+
+@pytest.fixture(scope="module")
+def gio():
+    import os
+
+    from tests.conftest import GOLDEN
+
+    with np.load(os.path.join(GOLDEN, "io.npz")) as z:
+        return {k: z[k] for k in z.files}
+
+
+@pytest.mark.parametrize("key,name,kwargs", [
+    ("cmvn_file/out_npy", "cmvn_stats.npy", {}),
+    ("cmvn_file/out_f64", "cmvn_stats.f64", {"force_as": "file"}),
+    ("cmvn_file/out_f32", "cmvn_stats.f32", {"force_as": "file"}),
+    ("cmvn_file/out_novar", "cmvn_stats.npy", {"norm_var": False}),
+])
+def test_cmvn_with_statistics_from_a_file(gio, key, name, kwargs):
+    import os
+
+    from tests.conftest import GOLDEN
+
+    st = Standardize(os.path.join(GOLDEN, name), **kwargs)
+    got = st.apply(gio["cmvn_file/in"])
+    assert got.dtype == np.float64
+    assert np.allclose(got, gio[key], rtol=1e-9, atol=1e-9)
+
+
+def test_stack_on_gpu_tensors_matches_reference(gio):
+    import torch
+
+    from pydrobert_speech_amd.post import Stack
+
+    x2, x3 = torch.from_numpy(gio["stack/in2"]).cuda(), torch.from_numpy(gio["stack/in3"]).cuda()
+    for key, x, kwargs, axis in [
+        ("stack/out2/nv3", x2, dict(num_vectors=3), 1),
+        ("stack/out2/nv3_edge", x2, dict(num_vectors=3, pad_mode="edge"), 1),
+        ("stack/out2/nv4_const", x2, dict(num_vectors=4, pad_mode="constant"), -1),
+        ("stack/out3/nv3_t1_a2", x3, dict(num_vectors=3, time_axis=1), 2),
+        ("stack/out3/nv2_tm1_a1", x3, dict(num_vectors=2, time_axis=-1), 1),
+    ]:
+        got = Stack(**kwargs).apply(x, axis=axis)
+        assert got.is_cuda and np.array_equal(got.cpu().numpy(), gio[key]), key
+    with pytest.raises(ValueError):
+        Stack(4, time_axis=1, pad_mode="reflect").apply(x3, axis=0)
+
+
+@pytest.mark.parametrize("pad_mode", [None, "constant", "edge"])
+@pytest.mark.parametrize("nv", [1, 3, 4])
+def test_stack_rows_matches_per_utterance_apply(nv, pad_mode):
+    import torch
+
+    from pydrobert_speech_amd.post import Stack
+
+    rng = np.random.default_rng(nv)
+    lens = [0, 1, nv, nv + 1, 250, 7, 1000]
+    rows = np.concatenate([[0], np.cumsum(lens)])
+    F = 41
+    feats = rng.standard_normal((rows[-1], F)).astype("f4")
+    st = Stack(nv, pad_mode=pad_mode)
+    got, new_rows = st.apply_rows(torch.from_numpy(feats).cuda(), rows)
+    got = got.cpu().numpy()
+    assert got.shape[1] == nv * F and new_rows[-1] == got.shape[0]
+    for b in range(len(lens)):
+        want = st.apply(feats[rows[b] : rows[b + 1]], axis=1)
+        assert np.array_equal(got[new_rows[b] : new_rows[b + 1]], want), (b, lens[b])
+    # strided input rows (a column slice of a wider buffer)
+    wide = torch.from_numpy(np.concatenate([feats, feats], 1)).cuda()
+    got2, _ = st.apply_rows(wide[:, :F], rows)
+    assert np.array_equal(got2.cpu().numpy(), got)
