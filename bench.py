@@ -58,6 +58,13 @@ WORKLOADS = {
                                   "sampling_rate": 48000}, "frame_length_ms": 20, "use_power": True},
         480000, 256, "cmvn",
     ),
+    # the headline bank without zero padding (N = L = 400 = 16 x 25)
+    "fbank40_nopad400_b1024x10s": (
+        {"name": "stft", "bank": {"name": "tri", "scaling_function": "mel", "num_filts": 40},
+         "frame_length_ms": 25, "frame_shift_ms": 10, "window_function": "hanning",
+         "use_power": True, "pad_to_nearest_power_of_two": False},
+        160000, 1024, None,
+    ),
 }
 DEFAULT_WORKLOAD = "fbank40_16k_25_10_b1024x10s"
 

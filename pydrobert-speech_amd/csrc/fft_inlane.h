@@ -159,6 +159,63 @@ PDS_HD void rdft_scaled(const float *a, float &even_sum, float &odd_sum, float *
   });
 }
 
+// cos / -sin of 2 pi K / M for the mixed-radix sizes (M divides 600)
+template <int M, int K>
+struct Tw600 {
+  static_assert(600 % M == 0, "second twiddle table covers divisors of 600");
+  static constexpr int idx = (((K % M) + M) % M) * (600 / M);
+  static constexpr float re = (float)kCos600[idx];
+  static constexpr float im = (float)(-kSin600[idx]);
+};
+
+constexpr bool is_pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
+
+// DFT of M real points for sizes that are not powers of two (M = 10, 20, 25, 30 ...), same
+// interface as rdft_scaled but UNSCALED outputs (Ar, Ai)[k], k = 1 .. (M - 1) / 2:
+//   even M: even_sum / odd_sum as in rdft_scaled;  odd M: even_sum = sum a[n], odd_sum = 0
+// Direct evaluation on the symmetric / antisymmetric halves of the input,
+//   Re A[k] = a[0] + sum_j (a[j] + a[M-j]) cos(2 pi j k / M)  (+ (-1)^k a[M/2]),
+//   Im A[k] =       - sum_j (a[j] - a[M-j]) sin(2 pi j k / M),      j = 1 .. (M - 1) / 2,
+// i.e. about M^2 / 2 fused multiply-adds with literal coefficients: for the M <= 30 in use this
+// is on a par with a mixed-radix network (25: 288 FMA) and has no data movement at all.
+template <int M>
+PDS_HD void rdft_direct(const float *a, float &even_sum, float &odd_sum, float *Ar, float *Ai) {
+  constexpr int J = (M - 1) / 2;
+  constexpr bool EVEN = M % 2 == 0;
+  float s[J + 1], d[J + 1];
+  static_for<1, J + 1>([&](auto jj) {
+    constexpr int j = decltype(jj)::value;
+    s[j] = a[j] + a[M - j];
+    d[j] = a[j] - a[M - j];
+  });
+  if constexpr (EVEN) {
+    float ev = a[0], od = 0.0f;
+    static_for<1, M>([&](auto nn) {
+      constexpr int n = decltype(nn)::value;
+      if constexpr (n % 2 == 0) ev += a[n]; else od += a[n];
+    });
+    even_sum = ev;
+    odd_sum = od;
+  } else {
+    float tot = a[0];
+    static_for<1, J + 1>([&](auto jj) { tot += s[decltype(jj)::value]; });
+    even_sum = tot;
+    odd_sum = 0.0f;
+  }
+  static_for<1, J + 1>([&](auto kk) {
+    constexpr int k = decltype(kk)::value;
+    float re = a[0], im = 0.0f;
+    if constexpr (EVEN) re += (k % 2 == 0) ? a[M / 2] : -a[M / 2];
+    static_for<1, J + 1>([&](auto jj) {
+      constexpr int j = decltype(jj)::value;
+      re += s[j] * Tw600<M, j * k>::re;
+      im += d[j] * Tw600<M, j * k>::im;
+    });
+    Ar[k] = re;
+    Ai[k] = im;
+  });
+}
+
 // DFT of M real points stored as z[m] = c[2m] + i c[2m+1] ALREADY transformed: given
 // Y = FFT_{M/2}(z), writes |A[m]|^2 (or |A[m]|) for m = 0 .. M/2, UNSCALED.
 template <int M, typename Emit>

@@ -113,21 +113,27 @@ __device__ __forceinline__ void wave_sync() {
 
 // N = N1 * N2: in-lane real DFT size x lanes per frame.  NROWS = ceil(L / N2) rows of N2
 // samples per frame, a compile-time constant so that the zero-padded tail is literal zeros.
+// N1 is a power of two (N = 128 .. 2048, radix-2 network) or, for transforms without zero
+// padding (pad_to_nearest_power_of_two = False: N = L = 160, 200, 240, 320, 400, 480, 640, 800,
+// 960), one of 20, 25, 30 evaluated directly; N2 is always a power of two.
 template <int N1, int N2, int NROWS>
 struct WaveGeom {
   static constexpr int N = N1 * N2;
-  static constexpr int H1 = N1 / 2;         // step-2 outputs k1 = 0..H1
-  static constexpr int CPL = H1 / N2;       // step-3 columns per lane
+  static constexpr int NREG = (N1 - 1) / 2;  // step-2 outputs that become regular columns: k1 = 1..NREG
+  static constexpr int COLS = NREG + 1;     // + column 0: the real-valued outputs (k1 = 0, and N1/2 if even)
+  static constexpr int CPL = (COLS + N2 - 1) / N2;  // step-3 columns per lane
+  static constexpr bool FULL = COLS % N2 == 0;      // every lane owns CPL columns (powers of two)
   static constexpr int GROUPS = 64 / N2;    // frames per wave iteration
   static constexpr int NB = N / 2 + 1;      // half-spectrum bins
   static constexpr int RS = N2 + 2;         // exchange row stride (float2): conflict-free
-  static constexpr int EXCH_F2 = GROUPS * H1 * RS;  // float2 per wave
+  static constexpr int EXCH_F2 = GROUPS * COLS * RS;  // float2 per wave
   // P row stride: >= NB + 1 (energy) and = 16 (mod 32) so that the two frames sharing a
   // 32-lane half write to disjoint banks
   static constexpr int PSTR = ((NB + 1 + 15) / 32) * 32 + 16;
   static_assert(GROUPS * PSTR <= EXCH_F2 * 2, "P must fit over the exchange area");
   static_assert(EXCH_F2 * 2 >= 64 * NROWS, "edge-frame gather reuses the exchange area");
-  static_assert(H1 % N2 == 0 && CPL >= 1 && N2 <= 32 && (RS * 8) % 16 == 0, "geometry");
+  static_assert(N % 2 == 0 && CPL >= 1 && N2 <= 32 && (RS * 8) % 16 == 0, "geometry");
+  static_assert(inl::is_pow2(N1) ? FULL : 600 % N1 == 0, "in-lane DFT sizes: 2^k, or a divisor of 600");
   static_assert(NROWS <= N1 && NROWS > 0, "rows");
 };
 
@@ -143,13 +149,13 @@ constexpr int USLOTS = 4;
 template <int N1, int N2, int NROWS, int MAXWAVES, int MINW, bool ELL_LDS, bool PRE>
 __global__ __launch_bounds__(MAXWAVES * 64, MINW) void stft_wave_kernel(const FastParams p) {
   using G = WaveGeom<N1, N2, NROWS>;
-  constexpr int N = G::N, H1 = G::H1, RS = G::RS, NB = G::NB, PSTR = G::PSTR;
+  constexpr int N = G::N, COLS = G::COLS, NREG = G::NREG, RS = G::RS, NB = G::NB, PSTR = G::PSTR;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int g = lane / N2, r = lane % N2;
   float *wbase = smem + wave * (G::EXCH_F2 * 2);
-  float2 *exch = reinterpret_cast<float2 *>(wbase) + g * H1 * RS;
+  float2 *exch = reinterpret_cast<float2 *>(wbase) + g * COLS * RS;
   float *Pg = wbase + g * PSTR;
   // filter table -> LDS once per workgroup (read by every wave, every iteration): per-slot
   // weight rows.  Tables too large for LDS (dense complex banks) stay in global memory and
@@ -170,12 +176,12 @@ __global__ __launch_bounds__(MAXWAVES * 64, MINW) void stft_wave_kernel(const Fa
 
   // per-lane constants, loop invariant: window slice and inter-stage twiddles
   float win[NROWS];
-  float twr[H1], twi[H1];
+  float twr[COLS], twi[COLS];
 #pragma unroll
   for (int n1 = 0; n1 < NROWS; ++n1) win[n1] = p.win_lane[r * N1 + n1];
 #pragma unroll
-  for (int k1 = 1; k1 < H1; ++k1) {
-    const float2 t = p.tw_lane[r * H1 + k1];
+  for (int k1 = 1; k1 <= NREG; ++k1) {
+    const float2 t = p.tw_lane[r * COLS + k1];
     twr[k1] = t.x;
     twi[k1] = t.y;
   }
@@ -316,28 +322,32 @@ __global__ __launch_bounds__(MAXWAVES * 64, MINW) void stft_wave_kernel(const Fa
 #pragma unroll
     for (int n1 = NROWS; n1 < N1; ++n1) a[n1] = 0.0f;
 
-    float even_sum, odd_sum, Ar[H1], Ai[H1];
+    float even_sum, odd_sum, Ar[COLS], Ai[COLS];
     if constexpr (PDS_ABLATE & 2) {
       even_sum = a[0];
       odd_sum = a[1];
 #pragma unroll
-      for (int k = 0; k < H1; ++k) {
+      for (int k = 0; k < COLS; ++k) {
         Ar[k] = a[2 * k];
         Ai[k] = a[2 * k + 1];
       }
-    } else {
+    } else if constexpr (inl::is_pow2(N1)) {
       inl::rdft_scaled<N1>(a, even_sum, odd_sum, Ar, Ai);
+    } else {
+      inl::rdft_direct<N1>(a, even_sum, odd_sum, Ar, Ai);
     }
 
     // transpose through LDS: row k1 of this frame's block holds column k1 for all n2; row 0
-    // holds c[j] = sum_q xw[j + 2 N2 q] (j < 2 N2), the input of the multiples of N1/2
+    // holds c[j] = sum_q xw[j + 2 N2 q] (j < 2 N2), the input of the multiples of N1/2.  (Odd
+    // N1: c[j] = sum_q xw[j + N2 q] for j < N2 and zeros above, whose 2 N2-point transform has
+    // the multiples of N1 at its even outputs; the odd ones are not bins and are dropped.)
     {
       float *row0 = reinterpret_cast<float *>(exch);
       row0[r] = even_sum;
       row0[N2 + r] = odd_sum;
     }
 #pragma unroll
-    for (int k1 = 1; k1 < H1; ++k1) {
+    for (int k1 = 1; k1 <= NREG; ++k1) {
       float2 v;
       v.x = Ar[k1] * twr[k1] - Ai[k1] * twi[k1];
       v.y = Ar[k1] * twi[k1] + Ai[k1] * twr[k1];
@@ -361,7 +371,7 @@ __global__ __launch_bounds__(MAXWAVES * 64, MINW) void stft_wave_kernel(const Fa
       for (int j = 0; j < N2 / 2; ++j) {
         float4 v;
         if constexpr (PDS_ABLATE & 4) {
-          v = make_float4(Ar[(2 * j) % H1], Ai[(2 * j) % H1], Ar[(2 * j + 1) % H1], Ai[(2 * j + 1) % H1]);
+          v = make_float4(Ar[(2 * j) % COLS], Ai[(2 * j) % COLS], Ar[(2 * j + 1) % COLS], Ai[(2 * j + 1) % COLS]);
         } else {
           v = row[j];
         }
@@ -443,23 +453,26 @@ __global__ __launch_bounds__(MAXWAVES * 64, MINW) void stft_wave_kernel(const Fa
     for (int q = 0; q < G::CPL; ++q) {
       const int kk = q * N2 + r;
       if (N2 != 16 && q == 0 && r == 0) {
+        // output m of the 2 N2-point transform is bin m N1 / 2 (odd N1: even m only)
 #pragma unroll
-        for (int m = 0; m <= N2; ++m) Pg[m * H1] = pw[q][m];
+        for (int m = 0; m <= N2; m += (N1 % 2 ? 2 : 1)) Pg[m * N1 / 2] = pw[q][m];
       } else {
         // (N2 == 16: lane 0 of q = 0 writes its meaningless column to multiples of N1, all of
-        // which the special bins written next overwrite)
+        // which the special bins written next overwrite).  Lanes beyond the last column (only
+        // when the columns do not fill the lanes) send theirs to the padding slot.
+        const bool live = G::FULL || kk < COLS;
 #pragma unroll
         for (int k2 = 0; k2 < N2; ++k2) {
           // bin kk + N1*k2, or its mirror image when beyond N/2
           const int bin = (k2 < N2 / 2) ? kk + N1 * k2 : N - kk - N1 * k2;
-          Pg[bin] = pw[q][k2];
+          Pg[live ? bin : PSTR - 1] = pw[q][k2];
         }
       }
     }
     if constexpr (N2 == 16) {
-      const bool has = r <= N2 / 2;
-      Pg[has ? r * H1 : PSTR - 1] = sp0;
-      Pg[has ? (N2 - r) * H1 : PSTR - 1] = sp1;
+      const bool has = r <= N2 / 2 && (N1 % 2 == 0 || r % 2 == 0);
+      Pg[has ? r * N1 / 2 : PSTR - 1] = sp0;
+      Pg[has ? (N2 - r) * N1 / 2 : PSTR - 1] = sp1;
     }
     // slots past the last bin are read (with weight 0) by the filter walk: keep them finite
 #pragma unroll
@@ -627,6 +640,9 @@ static int32_t launch_wave(const pds_stft_plan *plan, const BatchArgs &a) {
 // (e.g. 25 ms @ 16 kHz = 400 samples = 25 rows of 16) and round other lengths up.
 //   N = 128 : 16 x 8      N = 256 : 32 x 8      N = 512 : 32 x 16
 //   N = 1024: 64 x 16     N = 2048: 64 x 32
+// Transforms without zero padding (N = L, every row in use), N1 x N2:
+//   160: 20 x 8    200: 25 x 8    240: 30 x 8    320: 20 x 16   400: 25 x 16   480: 30 x 16
+//   640: 20 x 32   800: 25 x 32   960: 30 x 32
 #define PDS_GEOM_ROWS(N1, N2, R, MINW) \
   if (rows <= R) return launch_wave<N1, N2, R, MINW>(plan, a);
 
@@ -652,6 +668,15 @@ int32_t launch_stft_fast_f32(const pds_stft_plan *plan, const BatchArgs &a) {
       PDS_GEOM_ROWS(64, 32, 35, 2) PDS_GEOM_ROWS(64, 32, 38, 2) PDS_GEOM_ROWS(64, 32, 48, 2)
       PDS_GEOM_ROWS(64, 32, 64, 2)
       break;
+    case 160: PDS_GEOM_ROWS(20, 8, 20, 4) break;
+    case 200: PDS_GEOM_ROWS(25, 8, 25, 4) break;
+    case 240: PDS_GEOM_ROWS(30, 8, 30, 4) break;
+    case 320: PDS_GEOM_ROWS(20, 16, 20, 4) break;
+    case 400: PDS_GEOM_ROWS(25, 16, 25, 4) break;
+    case 480: PDS_GEOM_ROWS(30, 16, 30, 4) break;
+    case 640: PDS_GEOM_ROWS(20, 32, 20, 2) break;
+    case 800: PDS_GEOM_ROWS(25, 32, 25, 2) break;
+    case 960: PDS_GEOM_ROWS(30, 32, 30, 2) break;
     default:
       break;
   }
@@ -672,28 +697,41 @@ int32_t fast_tables_create(pds_stft_plan *plan, const double *window, const int3
     case 512: n1 = 32; n2 = 16; break;
     case 1024: n1 = 64; n2 = 16; break;
     case 2048: n1 = 64; n2 = 32; break;
+    case 160: n1 = 20; n2 = 8; break;
+    case 200: n1 = 25; n2 = 8; break;
+    case 240: n1 = 30; n2 = 8; break;
+    case 320: n1 = 20; n2 = 16; break;
+    case 400: n1 = 25; n2 = 16; break;
+    case 480: n1 = 30; n2 = 16; break;
+    case 640: n1 = 20; n2 = 32; break;
+    case 800: n1 = 25; n2 = 32; break;
+    case 960: n1 = 30; n2 = 32; break;
     default: return PDS_OK;  // generic kernel
   }
+  const bool pow2 = (n1 & (n1 - 1)) == 0;
+  // the mixed-radix geometries exist for transforms without zero padding only (N = L)
+  if (!pow2 && d.frame_length != d.dft_size) return PDS_OK;
   const char *off = std::getenv("PDS_STFT_GENERIC");
   if (off && off[0] == '1') return PDS_OK;
   if (d.frame_length > d.dft_size || d.frame_length <= d.dft_size / 2) return PDS_OK;
   // fast_log() skips the denormal rescue: a floor below the normal range stays on the generic path
   if (d.use_log && !((float)d.log_floor >= 1.17549435e-38f)) return PDS_OK;
   if (d.num_filts > 32767) return PDS_OK;
-  const int N = d.dft_size, H1 = n1 / 2;
+  const int N = d.dft_size, H1 = n1 / 2, cols = (n1 - 1) / 2 + 1;  // WaveGeom::COLS
   std::vector<float> win((size_t)n1 * n2, 0.0f);
   for (int r = 0; r < n2; ++r)
     for (int k = 0; k < n1; ++k) {
       const int idx = n2 * k + r;
       if (idx < d.frame_length) win[(size_t)r * n1 + k] = (float)window[idx];
     }
-  std::vector<float> tw((size_t)n2 * H1 * 2, 0.0f);
+  std::vector<float> tw((size_t)n2 * cols * 2, 0.0f);
   for (int r = 0; r < n2; ++r)
-    for (int k1 = 1; k1 < H1; ++k1) {
+    for (int k1 = 1; k1 < cols; ++k1) {
       const double ang = -2.0 * M_PI * (double)((r * k1) % N) / (double)N;
-      const double scale = (2 * k1 == H1) ? 1.0 : 0.5;  // undo rdft_scaled's factor
-      tw[((size_t)r * H1 + k1) * 2 + 0] = (float)(scale * std::cos(ang));
-      tw[((size_t)r * H1 + k1) * 2 + 1] = (float)(scale * std::sin(ang));
+      // undo rdft_scaled's factor (rdft_direct of the other sizes is unscaled)
+      const double scale = !pow2 ? 1.0 : (2 * k1 == H1) ? 1.0 : 0.5;
+      tw[((size_t)r * cols + k1) * 2 + 0] = (float)(scale * std::cos(ang));
+      tw[((size_t)r * cols + k1) * 2 + 1] = (float)(scale * std::sin(ang));
     }
   std::vector<int32_t> order(d.num_filts);
   for (int f = 0; f < d.num_filts; ++f) order[f] = f;

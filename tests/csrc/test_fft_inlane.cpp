@@ -63,11 +63,40 @@ static void check_rdft() {
   g_worst = fmax(g_worst, fmax(worst, worst_p) / sqrt((double)M));
 }
 
+// sizes that are not powers of two: unscaled outputs k = 1 .. (M - 1) / 2, and the column sums
+template <int M>
+static void check_rdft_direct() {
+  constexpr int J = (M - 1) / 2;
+  float a[M], Ar[J + 1] = {0}, Ai[J + 1] = {0}, ev, od;
+  for (int i = 0; i < M; ++i) a[i] = (float)frand();
+  rdft_direct<M>(a, ev, od, Ar, Ai);
+  double worst = 0, tot = 0, alt = 0;
+  for (int n = 0; n < M; ++n) {
+    tot += a[n];
+    alt += (n % 2 ? -1.0 : 1.0) * a[n];
+  }
+  worst = fabs(tot - (ev + od));
+  if (M % 2 == 0) worst = fmax(worst, fabs(alt - (ev - od)));
+  else worst = fmax(worst, fabs((double)od));
+  for (int k = 1; k <= J; ++k) {
+    double re = 0, im = 0;
+    for (int n = 0; n < M; ++n) {
+      re += a[n] * cos(2.0 * M_PI * n * k / M);
+      im -= a[n] * sin(2.0 * M_PI * n * k / M);
+    }
+    worst = fmax(worst, fmax(fabs(re - Ar[k]), fabs(im - Ai[k])));
+  }
+  printf("rdft_direct<%d> max abs err %.3g\n", M, worst);
+  g_worst = fmax(g_worst, worst / sqrt((double)M));
+}
+
 int main() {
   srand(12345);
   check_cfft<1>(); check_cfft<2>(); check_cfft<4>(); check_cfft<8>(); check_cfft<16>();
   check_cfft<32>(); check_cfft<64>(); check_cfft<128>();
   check_rdft<4>(); check_rdft<8>(); check_rdft<16>(); check_rdft<32>(); check_rdft<64>(); check_rdft<128>();
+  check_rdft_direct<10>(); check_rdft_direct<15>(); check_rdft_direct<20>(); check_rdft_direct<25>();
+  check_rdft_direct<30>(); check_rdft_direct<12>(); check_rdft_direct<50>();
   printf("worst normalised error %.3g\n", g_worst);
   return g_worst < 2e-6 ? 0 : 1;
 }

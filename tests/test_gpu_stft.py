@@ -209,6 +209,37 @@ EXTRA_GEOMETRIES = {
     "n256_tri_8k": {"name": "stft", "bank": {"name": "tri", "scaling_function": "linear", "num_filts": 17,
                     "sampling_rate": 8000, "scaling_function": {"name": "linear", "low_hz": 0.0}},
                     "frame_length_ms": 25, "use_log": False},
+    # ---- no zero padding: N = L, mixed-radix geometries N1 x N2 --------
+    # 400 = 25 x 16: the headline bank; 13 of the 16 lanes of a frame own a column
+    "nopad400_tri_mel40": {"name": "stft", "bank": {"name": "tri", "scaling_function": "mel", "num_filts": 40},
+                           "frame_length_ms": 25, "use_power": True, "pad_to_nearest_power_of_two": False},
+    # 320 = 20 x 16 (even in-lane size: Nyquist column too), energy, kaldi shift
+    "nopad320_fbank": {"name": "stft", "bank": {"name": "fbank", "num_filts": 23}, "frame_length_ms": 20,
+                       "include_energy": True, "use_power": True, "kaldi_shift": True,
+                       "pad_to_nearest_power_of_two": False},
+    # 480 = 30 x 16, complex bank with wrap-around filters, magnitude
+    "nopad480_gabor": {"name": "stft", "bank": {"name": "gabor", "scaling_function": "mel", "num_filts": 30},
+                       "frame_length_ms": 30, "use_power": False, "pad_to_nearest_power_of_two": False},
+    # 200 = 25 x 8 and 160 = 20 x 8 and 240 = 30 x 8 at 8 kHz (8 frames per wave)
+    "nopad200_tri_8k": {"name": "stft", "bank": {"name": "tri", "scaling_function": "bark", "num_filts": 15,
+                        "sampling_rate": 8000}, "frame_length_ms": 25, "use_power": True,
+                        "pad_to_nearest_power_of_two": False},
+    "nopad160_fbank_8k": {"name": "stft", "bank": {"name": "fbank", "num_filts": 10, "sampling_rate": 8000},
+                          "frame_length_ms": 20, "frame_shift_ms": 5, "frame_style": "causal", "use_power": True,
+                          "pad_to_nearest_power_of_two": False},
+    "nopad240_fbank_8k": {"name": "stft", "bank": {"name": "fbank", "num_filts": 12, "sampling_rate": 8000},
+                          "frame_length_ms": 30, "use_power": True, "include_energy": True, "use_log": False,
+                          "pad_to_nearest_power_of_two": False},
+    # 640 = 20 x 32, 800 = 25 x 32, 960 = 30 x 32 (two frames per wave)
+    "nopad640_tri_32k": {"name": "stft", "bank": {"name": "tri", "scaling_function": "mel", "num_filts": 45,
+                         "sampling_rate": 32000}, "frame_length_ms": 20, "use_power": True,
+                         "pad_to_nearest_power_of_two": False},
+    "nopad800_fbank_32k": {"name": "stft", "bank": {"name": "fbank", "num_filts": 64, "sampling_rate": 32000},
+                           "frame_length_ms": 25, "include_energy": True, "use_power": True,
+                           "pad_to_nearest_power_of_two": False},
+    "nopad960_gammatone_48k": {"name": "stft", "bank": {"name": "gammatone", "scaling_function": "mel",
+                               "num_filts": 24, "sampling_rate": 48000}, "frame_length_ms": 20, "use_power": True,
+                               "pad_to_nearest_power_of_two": False},
 }
 
 
