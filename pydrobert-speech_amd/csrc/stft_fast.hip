@@ -43,6 +43,9 @@ namespace pds {
 #ifndef PDS_ABLATE
 #define PDS_ABLATE 0
 #endif
+#ifndef PDS_FILTER_UNROLL
+#define PDS_FILTER_UNROLL 1
+#endif
 __device__ __forceinline__ void keep_alive(float v) { asm volatile("" ::"v"(v)); }
 
 struct FastParams {
@@ -514,6 +517,7 @@ __global__ __launch_bounds__(MAXWAVES * 64, MINW) void stft_wave_kernel(const Fa
       const int woff = slot_woff_ + r * (len + 4);  // + 4: conflict-free row skew
       float acc0 = 0.0f, acc1 = 0.0f, acc2 = 0.0f, acc3 = 0.0f;
       const float4 *wrow = reinterpret_cast<const float4 *>((ELL_LDS ? ellw_lds : p.ell_w) + woff);
+#pragma unroll PDS_FILTER_UNROLL
       for (int t4 = 0; t4 < ((PDS_ABLATE & 32) ? 2 : len / 4); t4 += 2) {
         const float4 w0 = wrow[t4], w1 = wrow[t4 + 1];
         const float4 p0 = prow[t4], p1 = prow[t4 + 1];
