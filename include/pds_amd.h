@@ -218,6 +218,47 @@ int32_t pds_cmvn_rows_f32out(const float *d_in, int64_t in_stride, const int64_t
                              int32_t norm_var, double *d_stats, float *d_out,
                              int64_t out_stride, int32_t *d_zero_var, void *stream);
 
+/* ---------------------------------------------------------------------------------
+ * ShortIntegrationFrameComputer (reference compute.py:613-996):
+ *   y_f[i] = sum_{k < M} taps[f][k] * sig[i + start - k]          (sig = 0 outside the utterance)
+ *   out[t][f] = log(max(sum_{m < 2S} window[m] * |y_f[t S + m]|^2 (or | |), log_floor))
+ * The plan holds what the reference derives in __init__ (compute.py:660-744): the translated
+ * impulse responses clamped to the longest support M (the "dirac" energy filter first when the
+ * computer includes energy, compute.py:701-710) and the 2S-sample integration window.
+ * --------------------------------------------------------------------------------- */
+typedef struct pds_si_desc {
+  int32_t frame_shift;   /* S (compute.py:674)                                         */
+  int32_t max_support;   /* M (compute.py:682-697)                                     */
+  int32_t num_coeffs;    /* filters + energy                                           */
+  int32_t taps_complex;  /* taps are (re, im) pairs (bank not real, compute.py:677)    */
+  int32_t use_power;     /* |y|^2 else |y| (compute.py:909-912)                        */
+  int32_t use_log;       /* compute.py:989-990                                         */
+  int32_t reserved;      /* must be 0                                                  */
+  int32_t reserved2;     /* must be 0                                                  */
+  double log_floor;      /* config.LOG_FLOOR_VALUE snapshot                            */
+} pds_si_desc;
+
+typedef struct pds_si_plan pds_si_plan;
+
+/* taps: host, double[num_coeffs][M] or double[num_coeffs][M][2]; window: host, double[2 S] */
+int32_t pds_si_plan_create(const pds_si_desc *desc, const double *taps, const double *window,
+                           pds_si_plan **plan_out);
+void pds_si_plan_destroy(pds_si_plan *plan);
+
+/* Batched compute_full (compute.py:852-855): arguments as pds_stft_batch_*.  d_nframes[b] is the
+ * number of frames to emit for utterance b (the host restates the reference's block arithmetic,
+ * compute.py:781-850); `start` is the stream position of the first integrated sample
+ * (skipped samples minus virtual leading zeros, compute.py:859-865) -- a caller that streams
+ * passes start + t0 * S to continue at frame t0. */
+int32_t pds_si_batch_f32(const pds_si_plan *plan, const float *d_signal, const int64_t *d_offsets,
+                         const int64_t *d_lengths, const int64_t *d_nframes,
+                         const int64_t *d_row_off, int32_t B, int64_t max_frames, int64_t start,
+                         float *d_out, int64_t out_stride, void *stream);
+int32_t pds_si_batch_f64(const pds_si_plan *plan, const double *d_signal, const int64_t *d_offsets,
+                         const int64_t *d_lengths, const int64_t *d_nframes,
+                         const int64_t *d_row_off, int32_t B, int64_t max_frames, int64_t start,
+                         double *d_out, int64_t out_stride, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -36,6 +36,26 @@ class StftDesc(Structure):
     ]
 
 
+class SiDesc(Structure):
+    # mirrors pds_si_desc (include/pds_amd.h)
+    _fields_ = [
+        ("frame_shift", c_int32),
+        ("max_support", c_int32),
+        ("num_coeffs", c_int32),
+        ("taps_complex", c_int32),
+        ("use_power", c_int32),
+        ("use_log", c_int32),
+        ("reserved", c_int32),
+        ("reserved2", c_int32),
+        ("log_floor", c_double),
+    ]
+
+
+_SI_BATCH_ARGS = [
+    c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int64, c_int64,
+    c_void_p, c_int64, c_void_p,
+]
+
 _BATCH_ARGS = [
     c_void_p,  # plan
     c_void_p,  # d_signal
@@ -97,6 +117,10 @@ SIGNATURES = {
         [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int32, c_int64, c_int32, c_int32,
          c_int32, c_void_p, c_int64, c_void_p],
     ),
+    "pds_si_plan_create": (c_int32, [POINTER(SiDesc), c_void_p, c_void_p, POINTER(c_void_p)]),
+    "pds_si_plan_destroy": (None, [c_void_p]),
+    "pds_si_batch_f32": (c_int32, _SI_BATCH_ARGS),
+    "pds_si_batch_f64": (c_int32, _SI_BATCH_ARGS),
     "pds_cmvn_scratch_len": (c_int64, [c_int64, c_int64]),
     "pds_cmvn_stats_f32": (c_int32, [c_void_p, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_void_p]),
     "pds_cmvn_stats_f64": (c_int32, [c_void_p, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_void_p]),
