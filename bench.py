@@ -65,6 +65,13 @@ WORKLOADS = {
          "use_power": True, "pad_to_nearest_power_of_two": False},
         160000, 1024, None,
     ),
+    # short-integration features, 40 complex Gabor filters (supports up
+    # to 380 taps) + energy; compute bound (direct time-domain filtering), so a smaller batch
+    "si_gabor40_b64x10s": (
+        {"name": "si", "bank": {"name": "gabor", "scaling_function": "mel", "num_filts": 40},
+         "include_energy": True, "use_power": True},
+        160000, 64, None,
+    ),
 }
 DEFAULT_WORKLOAD = "fbank40_16k_25_10_b1024x10s"
 
@@ -160,8 +167,9 @@ def main():
         B = args.batch
     comp = alias_factory_subclass_from_arg(ps.compute.FrameComputer, cfg)
 
+    is_si = isinstance(comp, ps.si.ShortIntegrationFrameComputer)
     cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and not is_si:
         cpu = cpu_baseline(comp, n)  # before the GPU is touched by this process
 
     import torch
@@ -189,8 +197,13 @@ def main():
     # synthetic batch: x = 3000 N(0,1), float32, seeded per rank; generated on the device
     g = torch.Generator(device=dev).manual_seed(1234 + rank)
     signal = torch.randn(B * n, generator=g, device=dev, dtype=torch.float32).mul_(3000.0)
-    layout = comp.prepare_layout(np.arange(B, dtype=np.int64) * n, np.full(B, n, dtype=np.int64), device=dev)
-    frames = layout.total_rows
+    offsets, lengths = np.arange(B, dtype=np.int64) * n, np.full(B, n, dtype=np.int64)
+    if is_si:
+        layout = None
+        frames = B * comp.num_frames(n)
+    else:
+        layout = comp.prepare_layout(offsets, lengths, device=dev)
+        frames = layout.total_rows
     C = comp.num_coeffs
     out_cols = 3 * C if post == "deltas2" else C
     out = torch.empty((frames, out_cols), dtype=torch.float32, device=dev)
@@ -200,6 +213,9 @@ def main():
 
     def step():
         nonlocal cmvn_out
+        if is_si:
+            comp.compute_packed(signal, offsets, lengths, out=out)
+            return
         comp.launch(signal, layout, out=out, generic=args.generic)
         if deltas is not None:  # statics were written with row stride 3C; deltas go beside them
             deltas.apply_rows(out[:, :C], layout.row_offsets, out=out)
@@ -293,7 +309,8 @@ def main():
                 "frames_per_gpu_per_step": frames, "num_coeffs": comp.num_coeffs, "post": post,
                 "frame_length": comp.frame_length, "frame_shift": comp.frame_shift,
                 "dft_size": comp.dft_size, "parallelism": f"utterance-sharded x{world}",
-                "kernel": "generic-direct-dft" if (args.generic or not comp.kernel_kind) else "fused-fft",
+                "kernel": "si-direct-fir" if is_si else
+                          "generic-direct-dft" if (args.generic or not comp.kernel_kind) else "fused-fft",
             },
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -305,6 +322,13 @@ def main():
             },
             "outputs_finite": finite,
         }
+        if is_si:
+            # compute bound: fused multiply-adds of the FIR bank per launch against the vector peak
+            # (157 TFLOP/s counts packed pairs; one FMA per lane and issue is half of that)
+            taps = comp.taps
+            fma = frames * comp.frame_shift * taps.shape[0] * taps.shape[1] * (1 if comp._real else 2)
+            line["compute"] = {"tflops": 2 * fma / k_avg_s / 1e12, "peak_fp32_valu_tflops": 78.6,
+                               "frac": 2 * fma / k_avg_s / 78.6e12, "fma_per_launch": fma}
         if cpu is not None:
             line["cpu_baseline"] = cpu
         if gather is not None:
