@@ -408,6 +408,13 @@ class ShortTimeFourierTransformFrameComputer(LinearFilterBankFrameComputer):
             raise ValueError("signal must be a contiguous 1-D tensor on the GPU")
         if layout.extent > signal.numel():
             raise ValueError("an utterance lies outside the signal buffer")
+        if signal.dtype == torch.float64 and config.FLOAT64_ARITHMETIC == "float32" and not generic:
+            # opt-in: float32 arithmetic for float64 data (config.FLOAT64_ARITHMETIC)
+            feats = self.launch(signal.to(torch.float32), layout, pad_left=pad_left, preemphasis=preemphasis)
+            if out is None:
+                return feats.to(torch.float64)
+            out[: feats.shape[0], : feats.shape[1]] = feats
+            return out
         if signal.dtype == torch.float32:
             fn = lib.pds_stft_batch_f32_generic if generic else lib.pds_stft_batch_f32
         elif signal.dtype == torch.float64:

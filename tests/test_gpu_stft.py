@@ -275,3 +275,24 @@ def test_nonfinite_samples_do_not_leak_into_other_frames(computers):
     contains = (t * S - pad <= 8000) & (8000 < t * S - pad + L)
     assert np.isnan(y[contains]).all()
     assert np.isfinite(y[~contains]).all()
+
+
+def test_float64_signals_can_opt_into_float32_arithmetic(computers, golden_stft, golden_meta, master_signal):
+    # config.FLOAT64_ARITHMETIC = "float32": float64 in, float64 out, fused float32 kernel inside
+    from pydrobert_speech_amd import config
+
+    comp = computers["c2_tri_mel40"]
+    n = max(golden_meta["lengths"]["c2_tri_mel40"])
+    x = master_signal[:n].astype("f8")
+    want = golden_stft[f"c2_tri_mel40/{n}/f8"]
+    exact = comp.compute_full(x)
+    assert exact.dtype == np.float64
+    assert_features_close(exact, want, rtol=1e-9, atol=1e-9)
+    config.FLOAT64_ARITHMETIC = "float32"
+    try:
+        fast = comp.compute_full(x)
+    finally:
+        config.FLOAT64_ARITHMETIC = "float64"
+    assert fast.dtype == np.float64 and fast.shape == want.shape
+    assert_features_close(fast, want, **F32)
+    assert np.abs(fast - want).max() > 1e-9  # it really was float32 arithmetic
