@@ -188,28 +188,53 @@ class FeatureDirWriter:
         import torch
 
         pool = concurrent.futures.ThreadPoolExecutor(num_workers) if num_workers else None
-        pending = [pool.submit(self.read, u, p) if pool else None for u, p in utt_path]
         done, i, n = 0, 0, len(utt_path)
+        pending, submitted = {}, 0  # reads in flight: at most two batches ahead of the GPU
+
+        def top_up():
+            nonlocal submitted
+            while pool and submitted < n and submitted < i + 2 * batch_utts:
+                pending[submitted] = pool.submit(self.read, *utt_path[submitted])
+                submitted += 1
+
+        writes = []  # (utt_id, future) of the batch before: files are written behind the GPU too
+
+        def settle():
+            nonlocal done
+            for utt_id, fut in writes:
+                fut.result()
+                if self.manifest is not None:  # listed only once the file is complete
+                    print(utt_id, file=self.manifest, flush=True)
+                done += 1
+            writes.clear()
+
         try:
             while i < n:
                 ids, signals, total = [], [], 0
                 first = i
                 while i < n and len(ids) < batch_utts and (not ids or total < batch_samples):
                     utt_id, path = utt_path[i]
-                    signal = pending[i].result() if pool else self.read(utt_id, path)
-                    pending[i] = None
+                    top_up()
+                    signal = pending.pop(i).result() if pool else self.read(utt_id, path)
                     ids.append(utt_id)
                     signals.append(signal)
                     total += len(signal)
                     i += 1
-                for utt_id, feat in zip(ids, self.process(signals, first)):
-                    torch.save(feat, os.path.join(self.out_dir, self.prefix + utt_id + self.suffix))
-                    if self.manifest is not None:
-                        print(utt_id, file=self.manifest, flush=True)
-                    done += 1
+                feats = self.process(signals, first)
+                settle()
+                for utt_id, feat in zip(ids, feats):
+                    path = os.path.join(self.out_dir, self.prefix + utt_id + self.suffix)
+                    if pool:
+                        writes.append((utt_id, pool.submit(torch.save, feat, path)))
+                    else:
+                        torch.save(feat, path)
+                        if self.manifest is not None:
+                            print(utt_id, file=self.manifest, flush=True)
+                        done += 1
+            settle()
         finally:
             if pool:
-                pool.shutdown(wait=False, cancel_futures=True)
+                pool.shutdown(wait=True, cancel_futures=True)
         return done
 
 
