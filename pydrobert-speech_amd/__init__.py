@@ -24,4 +24,5 @@ compute.SIFrameComputer = si.SIFrameComputer
 from ._native import LIB_PATH, NativeError  # noqa: F401
 
 __all__ = ["alias", "compute", "config", "filters", "post", "pre", "scales", "si", "util"]
+# ``pydrobert_speech_amd.torch`` (nn.Module faces) and ``.command_line`` import torch: on demand
 __version__ = "0.1.0"
