@@ -144,7 +144,8 @@ def main():
     ap.add_argument("--batch", type=int, default=None, help="utterances per GPU (default: workload's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true")
-    ap.add_argument("--generic", action="store_true", help="force the direct-DFT kernel")
+    ap.add_argument("--generic", action="store_true",
+                    help="force the direct-DFT kernel (si workloads: direct time-domain filtering)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl (= RCCL, one GPU per rank) or gloo (rehearsal: every rank on GPU 0, no gather)")
     args = ap.parse_args()
@@ -214,7 +215,7 @@ def main():
     def step():
         nonlocal cmvn_out
         if is_si:
-            comp.compute_packed(signal, offsets, lengths, out=out)
+            comp.compute_packed(signal, offsets, lengths, out=out, direct=args.generic)
             return
         comp.launch(signal, layout, out=out, generic=args.generic)
         if deltas is not None:  # statics were written with row stride 3C; deltas go beside them
@@ -309,7 +310,7 @@ def main():
                 "frames_per_gpu_per_step": frames, "num_coeffs": comp.num_coeffs, "post": post,
                 "frame_length": comp.frame_length, "frame_shift": comp.frame_shift,
                 "dft_size": comp.dft_size, "parallelism": f"utterance-sharded x{world}",
-                "kernel": "si-direct-fir" if is_si else
+                "kernel": ("si-direct-fir" if args.generic else "si-overlap-save-fft1024") if is_si else
                           "generic-direct-dft" if (args.generic or not comp.kernel_kind) else "fused-fft",
             },
             "roofline": {
@@ -327,8 +328,8 @@ def main():
             # (157 TFLOP/s counts packed pairs; one FMA per lane and issue is half of that)
             taps = comp.taps
             fma = frames * comp.frame_shift * taps.shape[0] * taps.shape[1] * (1 if comp._real else 2)
-            line["compute"] = {"tflops": 2 * fma / k_avg_s / 1e12, "peak_fp32_valu_tflops": 78.6,
-                               "frac": 2 * fma / k_avg_s / 78.6e12, "fma_per_launch": fma}
+            line["compute"] = {"direct_form_equivalent_tflops": 2 * fma / k_avg_s / 1e12,
+                               "peak_fp32_valu_tflops": 78.6, "direct_form_fma_per_launch": fma}
         if cpu is not None:
             line["cpu_baseline"] = cpu
         if gather is not None:

@@ -52,7 +52,37 @@ struct pds_stft_plan {
   pds::FastTables fast;
 };
 
+// Tables of the FFT form of the short-integration kernel (si_fft.hip); owned by the plan.
 namespace pds {
+struct SiFftTables {
+  int blocks = 0;              // shift-sized blocks each 1024-point transform yields (0: not available)
+  float2 *d_spectra = nullptr;  // [C][1024] filter spectra / 1024
+  float2 *d_twiddle = nullptr;  // [32][32] W_1024^(q * lane), row q
+  int num_cus = 0;
+};
+}  // namespace pds
+
+struct pds_si_plan {
+  pds_si_desc d;
+  int device = 0;
+  int mpad = 0;                  // taps per filter padded to a multiple of the register block
+  float *d_taps_f32 = nullptr;   // [C][mpad] (re) or [C][mpad][2] (re, im)
+  double *d_taps_f64 = nullptr;
+  float *d_window_f32 = nullptr;  // [2 S]
+  double *d_window_f64 = nullptr;
+  pds::SiFftTables fft;
+};
+
+namespace pds {
+
+// si_fft.hip
+int32_t si_fft_tables_create(pds_si_plan *plan, const double *taps);
+void si_fft_tables_destroy(pds_si_plan *plan);
+int64_t si_fft_scratch_len(const pds_si_plan *plan, int32_t B, int64_t max_frames);
+int32_t launch_si_fft(const pds_si_plan *plan, const float *d_signal, const int64_t *d_offsets,
+                      const int64_t *d_lengths, const int64_t *d_nframes, const int64_t *d_row_off,
+                      int32_t B, int64_t max_frames, int64_t start, float *d_scratch, float *d_out,
+                      int64_t out_stride, void *stream);
 
 struct BatchArgs {
   const void *d_signal;

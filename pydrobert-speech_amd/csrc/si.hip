@@ -28,16 +28,6 @@
 
 #include "pds_internal.h"
 
-struct pds_si_plan {
-  pds_si_desc d;
-  int device = 0;
-  int mpad = 0;                  // taps per filter padded to a multiple of the register block
-  float *d_taps_f32 = nullptr;   // [C][mpad] (re) or [C][mpad][2] (re, im)
-  double *d_taps_f64 = nullptr;
-  float *d_window_f32 = nullptr;  // [2 S]
-  double *d_window_f64 = nullptr;
-};
-
 namespace pds {
 
 static int32_t invalid_si(const char *msg) {
@@ -233,6 +223,7 @@ int32_t pds_si_plan_create(const pds_si_desc *desc, const double *taps, const do
   if (rc == PDS_OK) rc = pds::upload(&plan->d_taps_f32, t32.data(), t32.size());
   if (rc == PDS_OK) rc = pds::upload(&plan->d_window_f64, window, 2 * (size_t)d.frame_shift);
   if (rc == PDS_OK) rc = pds::upload(&plan->d_window_f32, w32.data(), w32.size());
+  if (rc == PDS_OK) rc = pds::si_fft_tables_create(plan, taps);
   if (rc != PDS_OK) {
     pds_si_plan_destroy(plan);
     return rc;
@@ -247,13 +238,22 @@ void pds_si_plan_destroy(pds_si_plan *plan) {
   (void)hipFree(plan->d_taps_f64);
   (void)hipFree(plan->d_window_f32);
   (void)hipFree(plan->d_window_f64);
+  pds::si_fft_tables_destroy(plan);
   delete plan;
+}
+
+int64_t pds_si_scratch_len(const pds_si_plan *plan, int32_t B, int64_t max_frames) {
+  return pds::si_fft_scratch_len(plan, B, max_frames);
 }
 
 int32_t pds_si_batch_f32(const pds_si_plan *plan, const float *d_signal, const int64_t *d_offsets,
                          const int64_t *d_lengths, const int64_t *d_nframes,
                          const int64_t *d_row_off, int32_t B, int64_t max_frames, int64_t start,
-                         float *d_out, int64_t out_stride, void *stream) {
+                         float *d_scratch, float *d_out, int64_t out_stride, void *stream) {
+  if (plan && d_scratch && plan->fft.blocks > 0 && B > 0 && B <= 65535 && max_frames > 0 && d_signal &&
+      d_offsets && d_lengths && d_nframes && d_row_off && d_out && out_stride >= plan->d.num_coeffs)
+    return pds::launch_si_fft(plan, d_signal, d_offsets, d_lengths, d_nframes, d_row_off, B, max_frames,
+                              start, d_scratch, d_out, out_stride, stream);
   return pds::launch_si<float>(plan, d_signal, d_offsets, d_lengths, d_nframes, d_row_off, B,
                                max_frames, start, d_out, out_stride, stream);
 }

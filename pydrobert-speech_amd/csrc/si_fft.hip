@@ -1,0 +1,266 @@
+// Short-integration features, FFT form (float32): the filter bank of csrc/si.hip evaluated by
+// overlap-save with 1024-point transforms, as the reference does it (compute.py:781-932), but with
+// a block size of this kernel's own choosing: a transform yields `blocks` whole shift-sized blocks
+// of filtered samples (blocks * S <= 1024 - (M - 1)), so every block's two window-weighted sums are
+// complete inside one transform and no accumulator crosses a transform boundary.
+//
+// A 1024-point complex FFT lives in HALF a wavefront: 32 lanes x 32 registers, element n in lane
+// n % 32, register n / 32.  One pass = in-lane FFT over the register index (fft_inlane.h), twiddle
+// W_1024^(lane * q), transposition through the half-wave's private LDS area, in-lane FFT again;
+// the result has the same layout (bin k in lane k % 32, register k / 32), so the inverse transform
+// is the same routine between two conjugations, and the spectra of the filters are read in natural
+// order, coalesced.  Per transform block: one forward FFT of the signal stretch (kept in LDS),
+// then per filter a pointwise product, an inverse FFT, |y|^2 times the two window halves into LDS,
+// and one 32-lane butterfly sum per (block, half).  The sums go to a scratch array
+// [utterance][block][coefficient][half]; a second, trivial kernel adds first-half(t) +
+// second-half(t + 1), applies the log and writes the features.  No workgroup barrier after the
+// tables are staged, no atomics; results are bitwise reproducible.
+//
+// Cost per filter and transform: ~1.3 k vector instructions per lane for `blocks` frames, against
+// 2 M S per frame for the direct form -- 10x fewer at M = 380, S = 160.
+#include <cmath>
+#include <vector>
+
+#include "fft_inlane.h"
+#include "pds_internal.h"
+
+namespace pds {
+
+namespace {
+
+constexpr int kN = 1024, kL = 32;       // transform size; lanes = registers = 32
+constexpr int kRowStride = kL + 1;      // exchange row stride in float2: conflict-free both ways
+constexpr int kWaves = 4;               // wavefronts per workgroup, two transforms each
+
+struct SiFftArgs {
+  const float *sig;
+  const int64_t *offsets, *lengths, *nframes;
+  float *scratch;
+  int64_t blocks_per_utt;   // scratch rows (shift-sized blocks) reserved per utterance
+  const float2 *spectra, *twiddle;
+  const float *window;
+  int64_t start;
+  int S, C, blocks, use_power;
+};
+
+__device__ __forceinline__ void half_wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// (zr, zi)[q] = element 32 q + l  ->  (zr, zi)[q] = bin 32 q + l of the 1024-point DFT
+__device__ __forceinline__ void fft1024(float (&zr)[kL], float (&zi)[kL], float2 *xch,
+                                        const float2 *tw, int l) {
+  float ar[kL], ai[kL];
+  inl::CFFT<kL, 1>::run(zr, zi, ar, ai);
+#pragma unroll
+  for (int q = 0; q < kL; ++q) {
+    const float2 t = tw[q * kL + l];  // W_1024^(l q)
+    float2 v;
+    v.x = ar[q] * t.x - ai[q] * t.y;
+    v.y = ar[q] * t.y + ai[q] * t.x;
+    xch[q * kRowStride + l] = v;
+  }
+  half_wave_sync();
+#pragma unroll
+  for (int q = 0; q < kL; ++q) {
+    const float2 v = xch[l * kRowStride + q];
+    ar[q] = v.x;
+    ai[q] = v.y;
+  }
+  half_wave_sync();
+  inl::CFFT<kL, 1>::run(ar, ai, zr, zi);
+}
+
+__global__ __launch_bounds__(kWaves * 64, 1) void si_fft_kernel(const SiFftArgs p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char si_fft_smem[];
+  float2 *tw = reinterpret_cast<float2 *>(si_fft_smem);                // [32][32]
+  float2 *xch_all = tw + kL * kL;                                      // [2 kWaves][32][33]
+  float2 *spec_all = xch_all + 2 * kWaves * kL * kRowStride;           // [2 kWaves][1024]
+  float *wexp = reinterpret_cast<float *>(spec_all + 2 * kWaves * kN);  // [2][V]: window halves, periodic
+  const int V = p.blocks * p.S;
+  for (int i = threadIdx.x; i < kL * kL; i += kWaves * 64) tw[i] = p.twiddle[i];
+  for (int i = threadIdx.x; i < V; i += kWaves * 64) {
+    wexp[i] = p.window[i % p.S];
+    wexp[V + i] = p.window[p.S + i % p.S];
+  }
+  __syncthreads();
+  const int half = threadIdx.x >> 5;       // 0 .. 2 kWaves - 1: one transform each
+  const int l = threadIdx.x & 31;
+  float2 *xch = xch_all + half * kL * kRowStride;
+  float2 *spec = spec_all + half * kN;
+  const int b = blockIdx.y;
+  const int64_t Tb = p.nframes[b];
+  const int64_t num_dft = (Tb + 1 + p.blocks - 1) / p.blocks;  // frames need blocks 0 .. Tb
+  const int64_t d = (int64_t)blockIdx.x * (2 * kWaves) + half;
+  // (both halves of a wave take the same branch or wave-level code below would deadlock: the
+  // half without work still walks through with a zero signal and stores nothing)
+  const bool has_work = d < num_dft;
+  if (__builtin_amdgcn_readfirstlane((int)__any(has_work)) == 0) return;
+  const int64_t n = p.lengths[b];
+  const float *x = p.sig + p.offsets[b];
+  // element m of the stretch is signal sample d V + start - (1024 - V) + m: the last V outputs of
+  // the circular convolution are the filtered samples d V .. d V + V - 1
+  const int64_t s0 = d * V + p.start - (kN - V);
+  float zr[kL], zi[kL];
+#pragma unroll
+  for (int q = 0; q < kL; ++q) {
+    const int64_t idx = s0 + q * kL + l;
+    zr[q] = (has_work && idx >= 0 && idx < n) ? x[idx] : 0.0f;
+    zi[q] = 0.0f;
+  }
+  fft1024(zr, zi, xch, tw, l);
+#pragma unroll
+  for (int q = 0; q < kL; ++q) spec[q * kL + l] = make_float2(zr[q], zi[q]);
+  half_wave_sync();
+  float *zw = reinterpret_cast<float *>(xch);  // [2][V] after the last transposition of a filter
+  float *srow = p.scratch + ((int64_t)b * p.blocks_per_utt + d * p.blocks) * p.C * 2;
+  const int first_valid = kN - V;
+  for (int c = 0; c < p.C; ++c) {
+    const float2 *h = p.spectra + (size_t)c * kN;
+    // conj(X H): the inverse transform is conj(FFT(conj(.))) (1 / 1024 is folded into H)
+#pragma unroll
+    for (int q = 0; q < kL; ++q) {
+      const float2 xs = spec[q * kL + l], hs = h[q * kL + l];
+      zr[q] = xs.x * hs.x - xs.y * hs.y;
+      zi[q] = -(xs.x * hs.y + xs.y * hs.x);
+    }
+    fft1024(zr, zi, xch, tw, l);
+    // |y|^2 (the conjugation does not matter) times the two window halves -> LDS
+#pragma unroll
+    for (int q = 0; q < kL; ++q) {
+      const int m = q * kL + l - first_valid;  // position inside the V filtered samples
+      float z = zr[q] * zr[q] + zi[q] * zi[q];
+      if (!p.use_power) z = __builtin_amdgcn_sqrtf(z);
+      if (m >= 0) {
+        zw[m] = z * wexp[m];
+        zw[V + m] = z * wexp[V + m];
+      }
+    }
+    half_wave_sync();
+    for (int task = 0; task < 2 * p.blocks; ++task) {
+      const int jj = task >> 1, hh = task & 1;
+      const float *src = zw + hh * V + jj * p.S;
+      float s = 0.0f;
+      for (int m = l; m < p.S; m += kL) s += src[m];
+#pragma unroll
+      for (int off = 16; off >= 1; off >>= 1) s += __shfl_xor(s, off, 64);
+      if (l == 0 && has_work) srow[((int64_t)jj * p.C + c) * 2 + hh] = s;
+    }
+    half_wave_sync();
+  }
+}
+
+// frame t = first-half sum of block t + second-half sum of block t + 1 (compute.py:980-990)
+__global__ __launch_bounds__(256) void si_combine_kernel(const float *scratch, int64_t blocks_per_utt,
+                                                         const int64_t *nframes, const int64_t *row_off,
+                                                         int C, int use_log, float log_floor, float *out,
+                                                         int64_t out_stride) {
+  const int b = blockIdx.y;
+  const int64_t Tb = nframes[b];
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= Tb * C) return;
+  const int64_t t = e / C;
+  const int c = (int)(e - t * C);
+  const float *base = scratch + ((int64_t)b * blocks_per_utt + t) * C * 2;
+  float val = base[c * 2] + base[(C + c) * 2 + 1];
+  if (use_log) val = logf(val < log_floor ? log_floor : val);  // NaN stays NaN
+  out[(row_off[b] + t) * out_stride + c] = val;
+}
+
+}  // namespace
+
+int32_t si_fft_tables_create(pds_si_plan *plan, const double *taps) {
+  SiFftTables &ft = plan->fft;
+  ft.blocks = 0;
+  const pds_si_desc &d = plan->d;
+  const int M = d.max_support, S = d.frame_shift, C = d.num_coeffs;
+  const int blocks = (kN - (M - 1)) / S;  // whole blocks in the alias-free part of a transform
+  if (M > kN || blocks < 1) return PDS_OK;  // supports too long for this form: direct kernel
+  // a half-wave's transposition area is reused for the V = blocks * S weighted samples, twice
+  if ((size_t)2 * blocks * S * sizeof(float) > (size_t)kL * kRowStride * sizeof(float2)) return PDS_OK;
+  std::vector<double> cs(kN), sn(kN);
+  for (int j = 0; j < kN; ++j) {
+    cs[j] = std::cos(2.0 * M_PI * j / kN);
+    sn[j] = std::sin(2.0 * M_PI * j / kN);
+  }
+  std::vector<float2> spectra((size_t)C * kN);
+  const int w = d.taps_complex ? 2 : 1;
+  for (int c = 0; c < C; ++c)
+    for (int k = 0; k < kN; ++k) {
+      double re = 0.0, im = 0.0;
+      for (int m = 0; m < M; ++m) {  // sum g[m] e^{-2 pi i k m / 1024}
+        const double gr = taps[((size_t)c * M + m) * w], gi = w == 2 ? taps[((size_t)c * M + m) * 2 + 1] : 0.0;
+        const int j = (int)(((int64_t)k * m) % kN);
+        re += gr * cs[j] + gi * sn[j];
+        im += gi * cs[j] - gr * sn[j];
+      }
+      spectra[(size_t)c * kN + k] = make_float2((float)(re / kN), (float)(im / kN));
+    }
+  std::vector<float2> tw((size_t)kL * kL);
+  for (int q = 0; q < kL; ++q)
+    for (int l = 0; l < kL; ++l)
+      tw[(size_t)q * kL + l] = make_float2((float)cs[(q * l) % kN], (float)(-sn[(q * l) % kN]));
+  int32_t rc = upload(&ft.d_spectra, spectra.data(), spectra.size());
+  if (rc == PDS_OK) rc = upload(&ft.d_twiddle, tw.data(), tw.size());
+  if (rc != PDS_OK) return rc;
+  hipDeviceProp_t prop;
+  PDS_HIP(hipGetDeviceProperties(&prop, plan->device));
+  ft.num_cus = prop.multiProcessorCount;
+  ft.blocks = blocks;
+  return PDS_OK;
+}
+
+void si_fft_tables_destroy(pds_si_plan *plan) {
+  (void)hipFree(plan->fft.d_spectra);
+  (void)hipFree(plan->fft.d_twiddle);
+  plan->fft = SiFftTables();
+}
+
+static int64_t transforms_for(const pds_si_plan *plan, int64_t max_frames) {
+  return (max_frames + 1 + plan->fft.blocks - 1) / plan->fft.blocks;
+}
+
+int64_t si_fft_scratch_len(const pds_si_plan *plan, int32_t B, int64_t max_frames) {
+  if (!plan || plan->fft.blocks == 0 || B <= 0 || max_frames <= 0) return 0;
+  return (int64_t)B * transforms_for(plan, max_frames) * plan->fft.blocks * plan->d.num_coeffs * 2;
+}
+
+int32_t launch_si_fft(const pds_si_plan *plan, const float *d_signal, const int64_t *d_offsets,
+                      const int64_t *d_lengths, const int64_t *d_nframes, const int64_t *d_row_off,
+                      int32_t B, int64_t max_frames, int64_t start, float *d_scratch, float *d_out,
+                      int64_t out_stride, void *stream) {
+  const pds_si_desc &d = plan->d;
+  const int64_t transforms = transforms_for(plan, max_frames);
+  SiFftArgs p;
+  p.sig = d_signal;
+  p.offsets = d_offsets;
+  p.lengths = d_lengths;
+  p.nframes = d_nframes;
+  p.scratch = d_scratch;
+  p.blocks_per_utt = transforms * plan->fft.blocks;
+  p.spectra = plan->fft.d_spectra;
+  p.twiddle = plan->fft.d_twiddle;
+  p.window = plan->d_window_f32;
+  p.start = start;
+  p.S = d.frame_shift;
+  p.C = d.num_coeffs;
+  p.blocks = plan->fft.blocks;
+  p.use_power = d.use_power;
+  const size_t smem = ((size_t)kL * kL + (size_t)2 * kWaves * kL * kRowStride + (size_t)2 * kWaves * kN) * sizeof(float2) +
+                      (size_t)2 * p.blocks * p.S * sizeof(float);
+  PDS_HIP(hipFuncSetAttribute((const void *)si_fft_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+  dim3 grid((unsigned)((transforms + 2 * kWaves - 1) / (2 * kWaves)), (unsigned)B);
+  hipLaunchKernelGGL(si_fft_kernel, grid, dim3(kWaves * 64), smem, (hipStream_t)stream, p);
+  PDS_HIP(hipGetLastError());
+  const int64_t items = max_frames * d.num_coeffs;
+  dim3 grid2((unsigned)((items + 255) / 256), (unsigned)B);
+  hipLaunchKernelGGL(si_combine_kernel, grid2, dim3(256), 0, (hipStream_t)stream, d_scratch,
+                     p.blocks_per_utt, d_nframes, d_row_off, d.num_coeffs, d.use_log, (float)d.log_floor,
+                     d_out, out_stride);
+  PDS_HIP(hipGetLastError());
+  return PDS_OK;
+}
+
+}  // namespace pds

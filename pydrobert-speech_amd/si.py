@@ -190,24 +190,39 @@ class ShortIntegrationFrameComputer(LinearFilterBankFrameComputer):
             self._plan = _SiPlan(desc, taps, self._window.reshape(-1))
         return self._plan
 
-    def compute_packed(self, signal, offsets, lengths, nframes=None, first_frame: int = 0, out=None):
+    def _launch(self, signal, meta, lo, hi, max_frames, start, out, direct=False):
+        """One native call for utterances ``lo:hi`` of the device index rows `meta`"""
+        torch = _native.require_device()
+        lib = _native.lib()
+        plan = self._native_plan()
+        stream = torch.cuda.current_stream(signal.device).cuda_stream
+        args = (plan.handle, signal.data_ptr(), meta[0, lo:].data_ptr(), meta[1, lo:].data_ptr(),
+                meta[2, lo:].data_ptr(), meta[3, lo:].data_ptr(), hi - lo, max_frames, start)
+        if signal.dtype == torch.float64:
+            rc = lib.pds_si_batch_f64(*args, out.data_ptr(), out.stride(0), stream)
+        else:
+            # float32: the overlap-save FFT form when the plan has it (it needs scratch memory),
+            # else -- or on request -- direct time-domain filtering
+            need = 0 if direct else int(lib.pds_si_scratch_len(plan.handle, hi - lo, max_frames))
+            scratch = torch.empty(need, dtype=torch.float32, device=signal.device) if need else None
+            rc = lib.pds_si_batch_f32(*args, scratch.data_ptr() if need else None, out.data_ptr(),
+                                      out.stride(0), stream)
+        _native.check(rc, "pds_si_batch")
+
+    def compute_packed(self, signal, offsets, lengths, nframes=None, first_frame: int = 0, out=None,
+                       direct: bool = False):
         """Features of a packed batch that is already on the GPU
 
         `signal`: contiguous 1-D float32 / float64 GPU tensor; utterance b is
         ``signal[offsets[b] : offsets[b] + lengths[b]]``.  `nframes` defaults to
         :func:`num_frames` of each length; `first_frame` continues every utterance at that frame
-        (streaming).  Returns ``(feats, row_offsets)`` like the STFT computer's method.
+        (streaming); `direct` forces time-domain filtering for float32 too (cross-checks).
+        Returns ``(feats, row_offsets)`` like the STFT computer's method.
         """
         torch = _native.require_device()
-        lib = _native.lib()
-        plan = self._native_plan()
         if not signal.is_cuda or signal.dim() != 1 or not signal.is_contiguous():
             raise ValueError("signal must be a contiguous 1-D tensor on the GPU")
-        if signal.dtype == torch.float32:
-            fn = lib.pds_si_batch_f32
-        elif signal.dtype == torch.float64:
-            fn = lib.pds_si_batch_f64
-        else:
+        if signal.dtype not in (torch.float32, torch.float64):
             raise TypeError("signal must be float32 or float64")
         lengths = np.asarray(lengths, dtype=np.int64).reshape(-1)
         offsets = np.asarray(offsets, dtype=np.int64).reshape(-1)
@@ -234,14 +249,10 @@ class ShortIntegrationFrameComputer(LinearFilterBankFrameComputer):
             return out, rows
         meta = torch.from_numpy(np.stack([offsets, lengths, nframes, rows[:-1]])).to(signal.device)
         start = self._skip0 - self._lead + int(first_frame) * self._frame_shift
-        stream = torch.cuda.current_stream(signal.device).cuda_stream
         with torch.cuda.device(signal.device):
             for lo in range(0, B, _MAX_UTTS_PER_CALL):
                 hi = min(B, lo + _MAX_UTTS_PER_CALL)
-                rc = fn(plan.handle, signal.data_ptr(), meta[0, lo:].data_ptr(), meta[1, lo:].data_ptr(),
-                        meta[2, lo:].data_ptr(), meta[3, lo:].data_ptr(), hi - lo, int(nframes[lo:hi].max()),
-                        start, out.data_ptr(), out.stride(0), stream)
-                _native.check(rc, "pds_si_batch")
+                self._launch(signal, meta, lo, hi, int(nframes[lo:hi].max()), start, out, direct)
         return out, rows
 
     @staticmethod
@@ -312,16 +323,10 @@ class ShortIntegrationFrameComputer(LinearFilterBankFrameComputer):
         start = self._skip0 - self._lead + self._done * S - self._tail_at
         work = np.ascontiguousarray(self._tail, dtype=self._work_dtype(self._stream_dtype))
         torch = _native.require_device()
-        lib = _native.lib()
-        plan = self._native_plan()
         d_sig = torch.from_numpy(work).to("cuda") if len(work) else torch.zeros(1, dtype=torch.from_numpy(work).dtype, device="cuda")
         out = torch.empty((count, self.num_coeffs), dtype=d_sig.dtype, device="cuda")
         meta = torch.tensor([[0], [len(work)], [count], [0]], dtype=torch.int64, device="cuda")
-        fn = lib.pds_si_batch_f32 if d_sig.dtype == torch.float32 else lib.pds_si_batch_f64
-        rc = fn(plan.handle, d_sig.data_ptr(), meta[0].data_ptr(), meta[1].data_ptr(), meta[2].data_ptr(),
-                meta[3].data_ptr(), 1, count, start, out.data_ptr(), out.stride(0),
-                torch.cuda.current_stream().cuda_stream)
-        _native.check(rc, "pds_si_batch")
+        self._launch(d_sig, meta, 0, 1, count, start, out)
         self._done += count
         # samples before the first one the next frame's filters can reach are no longer needed
         keep_from = max(self._tail_at, self._skip0 - self._lead + self._done * S - (self._max_support - 1))

@@ -107,6 +107,24 @@ def test_full_bank_long_signal_against_oracle():
         close(y, so.compute_full(x, p), **F32)
 
 
+def test_fft_and_direct_forms_agree_and_cover_the_fixtures(gsi):
+    # float32 takes the overlap-save FFT form by default; the direct form must give the same
+    # features (both within tolerance of the reference), for every fixture configuration
+    import torch
+
+    for name in NAMES:
+        comp = build(name)
+        n = META["lengths"][name][-1]
+        x = torch.from_numpy(gsi["master"][:n].astype("f4")).cuda()
+        fft, rows = comp.compute_packed(x, [0], [n])
+        direct, _ = comp.compute_packed(x, [0], [n], direct=True)
+        want = gsi[f"{name}/full/{n}/f4"]
+        assert rows.tolist() == [0, want.shape[0]]
+        close(fft.cpu().numpy(), want, **F32)
+        close(direct.cpu().numpy(), want, **F32)
+        close(fft.cpu().numpy(), direct.cpu().numpy(), **F32)
+
+
 def test_real_bank_with_long_supports_against_oracle():
     # triangular filters are real (half the multiplies) and long (support ~750 samples)
     comp = alias_factory_subclass_from_arg(
