@@ -142,6 +142,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default=DEFAULT_WORKLOAD, choices=sorted(WORKLOADS))
     ap.add_argument("--batch", type=int, default=None, help="utterances per GPU (default: workload's)")
+    ap.add_argument("--ragged", action="store_true",
+                    help="utterance lengths uniform in [1 s, 15 s] at the workload's rate (seed 99; "
+                         "SURVEY.md section 8(d)) instead of the workload's fixed length")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true")
     ap.add_argument("--generic", action="store_true",
@@ -197,11 +200,16 @@ def main():
 
     # synthetic batch: x = 3000 N(0,1), float32, seeded per rank; generated on the device
     g = torch.Generator(device=dev).manual_seed(1234 + rank)
-    signal = torch.randn(B * n, generator=g, device=dev, dtype=torch.float32).mul_(3000.0)
-    offsets, lengths = np.arange(B, dtype=np.int64) * n, np.full(B, n, dtype=np.int64)
+    if args.ragged:
+        rate = int(comp.sampling_rate)
+        lengths = np.random.default_rng(99 + rank).integers(rate, 15 * rate + 1, size=B).astype(np.int64)
+    else:
+        lengths = np.full(B, n, dtype=np.int64)
+    offsets = np.concatenate([[0], np.cumsum(lengths)[:-1]]).astype(np.int64)
+    signal = torch.randn(int(lengths.sum()), generator=g, device=dev, dtype=torch.float32).mul_(3000.0)
     if is_si:
         layout = None
-        frames = B * comp.num_frames(n)
+        frames = int(sum(comp.num_frames(int(v)) for v in lengths))
     else:
         layout = comp.prepare_layout(offsets, lengths, device=dev)
         frames = layout.total_rows
@@ -286,7 +294,7 @@ def main():
         try:
             with open(PMC_TRAFFIC_FILE) as fh:
                 rec = json.load(fh).get(args.workload)
-            if rec and rec["frames_per_launch"] == frames and not args.generic:
+            if rec and rec["frames_per_launch"] == frames and not args.generic and not args.ragged:
                 traffic_bytes = rec["hbm_bytes_per_launch"]
                 traffic = traffic_bytes / k_avg_s / 1e9
         except (OSError, ValueError, KeyError):
@@ -306,7 +314,8 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {
-                "workload": args.workload, "utterances_per_gpu": B, "samples_per_utterance": n,
+                "workload": args.workload + ("+ragged_1to15s" if args.ragged else ""), "utterances_per_gpu": B,
+                "samples_per_utterance": int(lengths.mean()),
                 "frames_per_gpu_per_step": frames, "num_coeffs": comp.num_coeffs, "post": post,
                 "frame_length": comp.frame_length, "frame_shift": comp.frame_shift,
                 "dft_size": comp.dft_size, "parallelism": f"utterance-sharded x{world}",
