@@ -18,6 +18,7 @@
 //
 // Cost per filter and transform: ~1.3 k vector instructions per lane for `blocks` frames, against
 // 2 M S per frame for the direct form -- 10x fewer at M = 380, S = 160.
+#include <algorithm>
 #include <cmath>
 #include <vector>
 
@@ -31,6 +32,13 @@ namespace {
 constexpr int kN = 1024, kL = 32;       // transform size; lanes = registers = 32
 constexpr int kRowStride = kL + 1;      // exchange row stride in float2: conflict-free both ways
 constexpr int kWaves = 4;               // wavefronts per workgroup, two transforms each
+constexpr int kMaxBlocks = 8;           // shift-sized blocks a transform may yield (register budget)
+
+// x + (x of the lane a DPP control word selects inside the 16-lane row)
+template <int CTRL>
+__device__ __forceinline__ float dpp_sum(float x) {
+  return x + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xf, 0xf, false));
+}
 
 struct SiFftArgs {
   const float *sig;
@@ -50,16 +58,17 @@ __device__ __forceinline__ void half_wave_sync() {
 }
 
 // (zr, zi)[q] = element 32 q + l  ->  (zr, zi)[q] = bin 32 q + l of the 1024-point DFT
+// (twr, twi)[q] = W_1024^(l q): the lane's twiddles live in registers -- with one wave per SIMD
+// there are 512 of them, and an LDS table read would be ordered against the transposition writes
 __device__ __forceinline__ void fft1024(float (&zr)[kL], float (&zi)[kL], float2 *xch,
-                                        const float2 *tw, int l) {
+                                        const float (&twr)[kL], const float (&twi)[kL], int l) {
   float ar[kL], ai[kL];
   inl::CFFT<kL, 1>::run(zr, zi, ar, ai);
 #pragma unroll
   for (int q = 0; q < kL; ++q) {
-    const float2 t = tw[q * kL + l];  // W_1024^(l q)
     float2 v;
-    v.x = ar[q] * t.x - ai[q] * t.y;
-    v.y = ar[q] * t.y + ai[q] * t.x;
+    v.x = ar[q] * twr[q] - ai[q] * twi[q];
+    v.y = ar[q] * twi[q] + ai[q] * twr[q];
     xch[q * kRowStride + l] = v;
   }
   half_wave_sync();
@@ -75,12 +84,10 @@ __device__ __forceinline__ void fft1024(float (&zr)[kL], float (&zi)[kL], float2
 
 __global__ __launch_bounds__(kWaves * 64, 1) void si_fft_kernel(const SiFftArgs p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char si_fft_smem[];
-  float2 *tw = reinterpret_cast<float2 *>(si_fft_smem);                // [32][32]
-  float2 *xch_all = tw + kL * kL;                                      // [2 kWaves][32][33]
+  float2 *xch_all = reinterpret_cast<float2 *>(si_fft_smem);          // [2 kWaves][32][33]
   float2 *spec_all = xch_all + 2 * kWaves * kL * kRowStride;           // [2 kWaves][1024]
   float *wexp = reinterpret_cast<float *>(spec_all + 2 * kWaves * kN);  // [2][V]: window halves, periodic
   const int V = p.blocks * p.S;
-  for (int i = threadIdx.x; i < kL * kL; i += kWaves * 64) tw[i] = p.twiddle[i];
   for (int i = threadIdx.x; i < V; i += kWaves * 64) {
     wexp[i] = p.window[i % p.S];
     wexp[V + i] = p.window[p.S + i % p.S];
@@ -103,6 +110,17 @@ __global__ __launch_bounds__(kWaves * 64, 1) void si_fft_kernel(const SiFftArgs 
   // element m of the stretch is signal sample d V + start - (1024 - V) + m: the last V outputs of
   // the circular convolution are the filtered samples d V .. d V + V - 1
   const int64_t s0 = d * V + p.start - (kN - V);
+  const int first_valid = kN - V;
+  float twr[kL], twi[kL], wa[kL], wb[kL];  // loop invariants of the lane (see fft1024)
+#pragma unroll
+  for (int q = 0; q < kL; ++q) {
+    const float2 t = p.twiddle[q * kL + l];
+    twr[q] = t.x;
+    twi[q] = t.y;
+    const int m = q * kL + l - first_valid;  // position inside the V filtered samples
+    wa[q] = m >= 0 ? wexp[m] : 0.0f;
+    wb[q] = m >= 0 ? wexp[V + m] : 0.0f;
+  }
   float zr[kL], zi[kL];
 #pragma unroll
   for (int q = 0; q < kL; ++q) {
@@ -110,44 +128,77 @@ __global__ __launch_bounds__(kWaves * 64, 1) void si_fft_kernel(const SiFftArgs 
     zr[q] = (has_work && idx >= 0 && idx < n) ? x[idx] : 0.0f;
     zi[q] = 0.0f;
   }
-  fft1024(zr, zi, xch, tw, l);
+  fft1024(zr, zi, xch, twr, twi, l);
 #pragma unroll
   for (int q = 0; q < kL; ++q) spec[q * kL + l] = make_float2(zr[q], zi[q]);
   half_wave_sync();
   float *zw = reinterpret_cast<float *>(xch);  // [2][V] after the last transposition of a filter
   float *srow = p.scratch + ((int64_t)b * p.blocks_per_utt + d * p.blocks) * p.C * 2;
-  const int first_valid = kN - V;
+  // the filter's spectrum is fetched one filter ahead: 32 loads in flight under the transform of
+  // the filter before instead of 32 round trips in front of this one
+  float hr[kL], hi[kL];
+#pragma unroll
+  for (int q = 0; q < kL; ++q) {
+    const float2 hs = p.spectra[q * kL + l];
+    hr[q] = hs.x;
+    hi[q] = hs.y;
+  }
   for (int c = 0; c < p.C; ++c) {
-    const float2 *h = p.spectra + (size_t)c * kN;
     // conj(X H): the inverse transform is conj(FFT(conj(.))) (1 / 1024 is folded into H)
 #pragma unroll
     for (int q = 0; q < kL; ++q) {
-      const float2 xs = spec[q * kL + l], hs = h[q * kL + l];
-      zr[q] = xs.x * hs.x - xs.y * hs.y;
-      zi[q] = -(xs.x * hs.y + xs.y * hs.x);
+      const float2 xs = spec[q * kL + l];
+      zr[q] = xs.x * hr[q] - xs.y * hi[q];
+      zi[q] = -(xs.x * hi[q] + xs.y * hr[q]);
     }
-    fft1024(zr, zi, xch, tw, l);
-    // |y|^2 (the conjugation does not matter) times the two window halves -> LDS
+    {
+      const float2 *h = p.spectra + (size_t)(c + 1 < p.C ? c + 1 : c) * kN;
+#pragma unroll
+      for (int q = 0; q < kL; ++q) {
+        const float2 hs = h[q * kL + l];
+        hr[q] = hs.x;
+        hi[q] = hs.y;
+      }
+    }
+    fft1024(zr, zi, xch, twr, twi, l);
+    // |y|^2 (the conjugation does not matter) times the two window halves -> LDS; samples before
+    // the alias-free part go to a dump slot behind the two arrays (no branches in this loop)
 #pragma unroll
     for (int q = 0; q < kL; ++q) {
       const int m = q * kL + l - first_valid;  // position inside the V filtered samples
       float z = zr[q] * zr[q] + zi[q] * zi[q];
       if (!p.use_power) z = __builtin_amdgcn_sqrtf(z);
-      if (m >= 0) {
-        zw[m] = z * wexp[m];
-        zw[V + m] = z * wexp[V + m];
-      }
+      zw[m >= 0 ? m : 2 * V] = z * wa[q];
+      zw[m >= 0 ? V + m : 2 * V] = z * wb[q];
     }
     half_wave_sync();
-    for (int task = 0; task < 2 * p.blocks; ++task) {
-      const int jj = task >> 1, hh = task & 1;
-      const float *src = zw + hh * V + jj * p.S;
-      float s = 0.0f;
-      for (int m = l; m < p.S; m += kL) s += src[m];
+    // every lane first gathers its share of all 2 * blocks sums (independent LDS reads), then the
+    // 32-lane butterflies of all of them run side by side: four DPP steps inside the 16-lane rows
+    // and one exchange between the two rows of the half-wave
+    float part[2 * kMaxBlocks];
 #pragma unroll
-      for (int off = 16; off >= 1; off >>= 1) s += __shfl_xor(s, off, 64);
-      if (l == 0 && has_work) srow[((int64_t)jj * p.C + c) * 2 + hh] = s;
+    for (int task = 0; task < 2 * kMaxBlocks; ++task) {
+      part[task] = 0.0f;
+      if (task < 2 * p.blocks) {
+        const float *src = zw + (task & 1) * V + (task >> 1) * p.S;
+        for (int m = l; m < p.S; m += kL) part[task] += src[m];
+      }
     }
+#pragma unroll
+    for (int task = 0; task < 2 * kMaxBlocks; ++task) {
+      float v = part[task];
+      v = dpp_sum<0xB1>(v);   // quad_perm [1,0,3,2]
+      v = dpp_sum<0x4E>(v);   // quad_perm [2,3,0,1]
+      v = dpp_sum<0x141>(v);  // row_half_mirror
+      v = dpp_sum<0x140>(v);  // row_mirror
+      part[task] = v;
+    }
+#pragma unroll
+    for (int task = 0; task < 2 * kMaxBlocks; ++task) part[task] += __shfl_xor(part[task], 16, 64);
+#pragma unroll
+    for (int task = 0; task < 2 * kMaxBlocks; ++task)
+      if (task < 2 * p.blocks && l == 0 && has_work)
+        srow[((int64_t)(task >> 1) * p.C + c) * 2 + (task & 1)] = part[task];
     half_wave_sync();
   }
 }
@@ -176,10 +227,11 @@ int32_t si_fft_tables_create(pds_si_plan *plan, const double *taps) {
   ft.blocks = 0;
   const pds_si_desc &d = plan->d;
   const int M = d.max_support, S = d.frame_shift, C = d.num_coeffs;
-  const int blocks = (kN - (M - 1)) / S;  // whole blocks in the alias-free part of a transform
+  // whole blocks in the alias-free part of a transform
+  const int blocks = std::min(kMaxBlocks, (kN - (M - 1)) / S);
   if (M > kN || blocks < 1) return PDS_OK;  // supports too long for this form: direct kernel
   // a half-wave's transposition area is reused for the V = blocks * S weighted samples, twice
-  if ((size_t)2 * blocks * S * sizeof(float) > (size_t)kL * kRowStride * sizeof(float2)) return PDS_OK;
+  if (((size_t)2 * blocks * S + 1) * sizeof(float) > (size_t)kL * kRowStride * sizeof(float2)) return PDS_OK;
   std::vector<double> cs(kN), sn(kN);
   for (int j = 0; j < kN; ++j) {
     cs[j] = std::cos(2.0 * M_PI * j / kN);
@@ -248,7 +300,7 @@ int32_t launch_si_fft(const pds_si_plan *plan, const float *d_signal, const int6
   p.C = d.num_coeffs;
   p.blocks = plan->fft.blocks;
   p.use_power = d.use_power;
-  const size_t smem = ((size_t)kL * kL + (size_t)2 * kWaves * kL * kRowStride + (size_t)2 * kWaves * kN) * sizeof(float2) +
+  const size_t smem = ((size_t)2 * kWaves * kL * kRowStride + (size_t)2 * kWaves * kN) * sizeof(float2) +
                       (size_t)2 * p.blocks * p.S * sizeof(float);
   PDS_HIP(hipFuncSetAttribute((const void *)si_fft_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
   dim3 grid((unsigned)((transforms + 2 * kWaves - 1) / (2 * kWaves)), (unsigned)B);
