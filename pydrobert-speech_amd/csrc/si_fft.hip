@@ -85,8 +85,7 @@ __device__ __forceinline__ void fft1024(float (&zr)[kL], float (&zi)[kL], float2
 __global__ __launch_bounds__(kWaves * 64, 1) void si_fft_kernel(const SiFftArgs p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char si_fft_smem[];
   float2 *xch_all = reinterpret_cast<float2 *>(si_fft_smem);          // [2 kWaves][32][33]
-  float2 *spec_all = xch_all + 2 * kWaves * kL * kRowStride;           // [2 kWaves][1024]
-  float *wexp = reinterpret_cast<float *>(spec_all + 2 * kWaves * kN);  // [2][V]: window halves, periodic
+  float *wexp = reinterpret_cast<float *>(xch_all + 2 * kWaves * kL * kRowStride);  // [2][V]: window halves, periodic
   const int V = p.blocks * p.S;
   for (int i = threadIdx.x; i < V; i += kWaves * 64) {
     wexp[i] = p.window[i % p.S];
@@ -96,7 +95,6 @@ __global__ __launch_bounds__(kWaves * 64, 1) void si_fft_kernel(const SiFftArgs 
   const int half = threadIdx.x >> 5;       // 0 .. 2 kWaves - 1: one transform each
   const int l = threadIdx.x & 31;
   float2 *xch = xch_all + half * kL * kRowStride;
-  float2 *spec = spec_all + half * kN;
   const int b = blockIdx.y;
   const int64_t Tb = p.nframes[b];
   const int64_t num_dft = (Tb + 1 + p.blocks - 1) / p.blocks;  // frames need blocks 0 .. Tb
@@ -129,9 +127,12 @@ __global__ __launch_bounds__(kWaves * 64, 1) void si_fft_kernel(const SiFftArgs 
     zi[q] = 0.0f;
   }
   fft1024(zr, zi, xch, twr, twi, l);
+  float xr[kL], xi[kL];  // the stretch's spectrum stays in the lane's registers for every filter
 #pragma unroll
-  for (int q = 0; q < kL; ++q) spec[q * kL + l] = make_float2(zr[q], zi[q]);
-  half_wave_sync();
+  for (int q = 0; q < kL; ++q) {
+    xr[q] = zr[q];
+    xi[q] = zi[q];
+  }
   float *zw = reinterpret_cast<float *>(xch);  // [2][V] after the last transposition of a filter
   float *srow = p.scratch + ((int64_t)b * p.blocks_per_utt + d * p.blocks) * p.C * 2;
   // the filter's spectrum is fetched one filter ahead: 32 loads in flight under the transform of
@@ -147,9 +148,8 @@ __global__ __launch_bounds__(kWaves * 64, 1) void si_fft_kernel(const SiFftArgs 
     // conj(X H): the inverse transform is conj(FFT(conj(.))) (1 / 1024 is folded into H)
 #pragma unroll
     for (int q = 0; q < kL; ++q) {
-      const float2 xs = spec[q * kL + l];
-      zr[q] = xs.x * hr[q] - xs.y * hi[q];
-      zi[q] = -(xs.x * hi[q] + xs.y * hr[q]);
+      zr[q] = xr[q] * hr[q] - xi[q] * hi[q];
+      zi[q] = -(xr[q] * hi[q] + xi[q] * hr[q]);
     }
     {
       const float2 *h = p.spectra + (size_t)(c + 1 < p.C ? c + 1 : c) * kN;
@@ -300,7 +300,7 @@ int32_t launch_si_fft(const pds_si_plan *plan, const float *d_signal, const int6
   p.C = d.num_coeffs;
   p.blocks = plan->fft.blocks;
   p.use_power = d.use_power;
-  const size_t smem = ((size_t)2 * kWaves * kL * kRowStride + (size_t)2 * kWaves * kN) * sizeof(float2) +
+  const size_t smem = ((size_t)2 * kWaves * kL * kRowStride) * sizeof(float2) +
                       (size_t)2 * p.blocks * p.S * sizeof(float);
   PDS_HIP(hipFuncSetAttribute((const void *)si_fft_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
   dim3 grid((unsigned)((transforms + 2 * kWaves - 1) / (2 * kWaves)), (unsigned)B);
