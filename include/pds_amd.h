@@ -78,8 +78,9 @@ int32_t pds_stft_num_coeffs(const pds_stft_plan *plan);
 /* frames compute_full yields for a signal of n samples: 0 if n < L/2 + 1, else
  * (n + S/2) / S (compute.py:580-581, 596) */
 int64_t pds_stft_num_frames(const pds_stft_plan *plan, int64_t n);
-/* which kernel family the plan dispatches to for float32 input: 1 = fused LDS/register
- * FFT kernel (power-of-two N it is instantiated for), 0 = generic direct-DFT kernel */
+/* which kernel family the plan dispatches to for float32 input: the DFT size when a fused
+ * LDS/register FFT geometry serves it (128 .. 2048, or an unpadded N = L of 160 .. 960),
+ * 0 = generic direct-DFT kernel */
 int32_t pds_stft_plan_kernel_kind(const pds_stft_plan *plan);
 
 /*
