@@ -79,15 +79,16 @@ __global__ __launch_bounds__(kSiThreads) void si_conv_kernel(const SiArgs<T> p) 
     seg[e] = (idx >= 0 && idx < n) ? x[idx] : (T)0;
   }
   __syncthreads();
-  const int first = tid * R;              // the thread's first sample inside the tile
-  const bool active = first < tile;
-  const int base = p.mpad - 1 + first;    // its position in `seg` for tap 0
   T *obase = p.out + (p.row_off[b] + j0) * p.out_stride;
   for (int c = 0; c < p.C; ++c) {
+   // (a tile longer than kSiThreads * R samples -- frame shifts beyond ~1150 samples -- takes
+   // several passes of the thread block)
+   for (int first = tid * R; first < tile; first += kSiThreads * R) {
+    const int base = p.mpad - 1 + first;    // the thread's position in `seg` for tap 0
     T yr[R], yi[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) yr[r] = yi[r] = (T)0;
-    if (active) {
+    {
       const T *g = p.taps + (size_t)c * p.mpad * (COMPLEX ? 2 : 1);
       for (int kb = 0; kb < p.mpad; kb += R) {
         T v[2 * R - 1];  // v[q] = sample (q - (R - 1)) positions after the one tap kb reaches
@@ -124,6 +125,7 @@ __global__ __launch_bounds__(kSiThreads) void si_conv_kernel(const SiArgs<T> p) 
         m = m + 1 == S ? 0 : m + 1;
       }
     }
+   }
     __syncthreads();
     // (block jj, half h): strided partial sums, then a butterfly over the wave (fixed order)
     for (int task = wave; task < 2 * JB; task += kSiThreads / 64) {
@@ -161,7 +163,7 @@ static int32_t launch_si(const pds_si_plan *plan, const T *d_signal, const int64
   if (out_stride < d.num_coeffs) return invalid_si("si_batch: out_stride < num_coeffs");
   const int S = d.frame_shift;
   int JB = (kSiThreads * kSiR) / S;
-  if (JB < 2) return invalid_si("si_batch: frame shift too long for one workgroup tile");
+  if (JB < 2) JB = 2;  // long shifts: two blocks per tile, several passes of the thread block
   if ((int64_t)JB - 1 > max_frames) JB = (int)max_frames + 1;
   const int tile = JB * S;
   const size_t smem = ((size_t)tile + plan->mpad - 1 + kSiR + 2 * (size_t)tile + 2 * (size_t)JB) * sizeof(T);

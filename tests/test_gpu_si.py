@@ -134,3 +134,20 @@ def test_real_bank_with_long_supports_against_oracle():
                     comp._window.reshape(-1), comp.frame_style == "centered", False, False)
     x = (np.random.default_rng(4).standard_normal(9000) * 100).astype("f8")
     close(comp.compute_full(x), so.compute_full(x, p), rtol=1e-9, atol=1e-9)
+
+
+def test_long_frame_shift_takes_several_passes():
+    # 50 ms at 48 kHz = 2400 samples per block: beyond one pass of the direct kernel's thread block
+    # and beyond the FFT form's 1024-point transforms (which then declines: scratch length 0)
+    comp = alias_factory_subclass_from_arg(
+        FrameComputer, {"name": "si", "bank": {"name": "gabor", "scaling_function": "mel", "num_filts": 4,
+                                               "sampling_rate": 48000}, "frame_shift_ms": 50, "use_power": True})
+    assert comp.frame_shift == 2400
+    p = so.SiParams(comp.frame_shift, comp._max_support, comp._translation, comp.dft_size, comp.taps,
+                    comp._window.reshape(-1), comp.frame_style == "centered", True, True)
+    rng = np.random.default_rng(11)
+    for n in (30000, 2399, 7201):
+        x = (rng.standard_normal(n) * 1000).astype("f4")
+        close(comp.compute_full(x), so.compute_full(x, p), **F32)
+    x8 = (rng.standard_normal(12000) * 1000).astype("f8")
+    close(comp.compute_full(x8), so.compute_full(x8, p), rtol=1e-9, atol=1e-9)
