@@ -1,0 +1,145 @@
+#!/usr/bin/env python3
+"""Randomised differential test: GPU kernels against the pinned oracle over random configurations.
+
+    python tools/fuzz_parity.py [num_configs] [seed]        (GPU box)
+
+Draws frame computers the way a user could configure them (bank family, scale, filter count,
+sampling rate, frame length / shift, style, window, energy / power / log flags, zero padding),
+runs a ragged batch through the fused kernel (and the direct-DFT kernel) and compares with
+oracle/stft_oracle.py; every tenth configuration is a short-integration computer checked against
+oracle/si_oracle.py.  Prints one line per failure and a summary; exit code 1 on any failure.
+"""
+import json
+import os
+import sys
+import traceback
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import pydrobert_speech_amd as ps  # noqa: E402
+from oracle import si_oracle as so  # noqa: E402
+from oracle import stft_oracle as orc  # noqa: E402
+from pydrobert_speech_amd.alias import alias_factory_subclass_from_arg  # noqa: E402
+
+
+def draw_bank(rng, rate):
+    kind = rng.choice(["tri", "fbank", "gabor", "gammatone"])
+    cfg = {"name": str(kind), "sampling_rate": rate, "num_filts": int(rng.integers(3, 48))}
+    if kind != "fbank":
+        cfg["scaling_function"] = str(rng.choice(["mel", "bark"]))
+    if kind == "tri" and rng.random() < 0.3:
+        cfg["analytic"] = True
+    if kind in ("gabor", "gammatone") and rng.random() < 0.3:
+        cfg["erb"] = True
+    return cfg
+
+
+def draw_stft(rng):
+    rate = int(rng.choice([8000, 16000, 22050, 32000, 44100, 48000]))
+    ms = float(rng.choice([10, 12.5, 16, 20, 25, 30, 32, 40]))
+    cfg = {"name": "stft", "bank": draw_bank(rng, rate), "frame_length_ms": ms,
+           "frame_shift_ms": float(rng.choice([5, 8, 10, 12.5, 16])),
+           "use_power": bool(rng.random() < 0.7), "use_log": bool(rng.random() < 0.8),
+           "include_energy": bool(rng.random() < 0.4), "kaldi_shift": bool(rng.random() < 0.3),
+           "pad_to_nearest_power_of_two": bool(rng.random() < 0.75)}
+    if rng.random() < 0.5:
+        cfg["frame_style"] = str(rng.choice(["causal", "centered"]))
+    if rng.random() < 0.6:
+        cfg["window_function"] = str(rng.choice(["hanning", "hamming", "blackman", "bartlett", "rect", "gamma"]))
+    return cfg
+
+
+def draw_si(rng):
+    rate = int(rng.choice([8000, 16000]))
+    cfg = {"name": "si", "bank": draw_bank(rng, rate), "frame_shift_ms": float(rng.choice([5, 10, 12.5, 20])),
+           "use_power": bool(rng.random() < 0.5), "use_log": bool(rng.random() < 0.8),
+           "include_energy": bool(rng.random() < 0.4)}
+    cfg["bank"]["num_filts"] = int(rng.integers(2, 8))
+    if cfg["bank"]["name"] == "fbank":  # supports of thousands of taps: keep the run short
+        cfg["bank"]["name"] = "tri"
+        cfg["bank"]["scaling_function"] = "mel"
+    return cfg
+
+
+def close(got, want, rtol, atol):
+    got, want = np.asarray(got, np.float64), np.asarray(want, np.float64)
+    if got.shape != want.shape:
+        return False, f"shape {got.shape} vs {want.shape}"
+    if not want.size:
+        return True, ""
+    nan = np.isnan(want)
+    if (np.isnan(got) != nan).any():
+        return False, "nan pattern"
+    scale = np.maximum(np.abs(want), np.abs(want[~nan]).max() * 1e-3 if (~nan).any() else 1.0)
+    err = np.abs(got - want)
+    bad = (err > atol + rtol * scale) & ~nan
+    return (not bad.any()), f"{int(bad.sum())} bad, max err {np.nanmax(err):.3g}"
+
+
+def main():
+    import torch
+
+    count = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+    rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+    fails, kinds = 0, {}
+    for i in range(count):
+        cfg = draw_si(rng) if i % 10 == 9 else draw_stft(rng)
+        try:
+            comp = alias_factory_subclass_from_arg(ps.compute.FrameComputer, json.loads(json.dumps(cfg)))
+        except Exception as exc:  # invalid draws (e.g. filters above Nyquist) are not failures
+            kinds["invalid"] = kinds.get("invalid", 0) + 1
+            continue
+        if cfg["name"] == "stft" and comp.pad_left < 0:
+            # kaldi_shift with a shift longer than the frame: the reference's numpy.pad raises on
+            # the negative width (compute.py:584-600), and so does plan creation here
+            kinds["negative_pad"] = kinds.get("negative_pad", 0) + 1
+            continue
+        try:
+            S = comp.frame_shift
+            L = comp.frame_length
+            lens = [0, 1, L // 2, L // 2 + 1, L, L + S - 1, int(rng.integers(L, 40 * S + L)), int(rng.integers(1, 3 * L))]
+            sigs = [(3000 * rng.standard_normal(n)).astype("f4") for n in lens]
+            if cfg["name"] == "si":
+                p = so.SiParams(S, comp._max_support, comp._translation, comp.dft_size, comp.taps,
+                                comp._window.reshape(-1), comp.frame_style == "centered", comp._power, comp._log)
+                got = comp.compute_full_batch(sigs)
+                want = [so.compute_full(x, p) for x in sigs]
+                kind = "si"
+                tol = dict(rtol=3e-4, atol=3e-5)
+            else:
+                p = orc.StftParams(
+                    frame_length=L, frame_shift=S, dft_size=comp.dft_size, window=np.asarray(comp._window),
+                    starts=list(comp._filt_start_idxs), taps=[np.asarray(t) for t in comp._truncated_filts],
+                    is_real=comp.bank.is_real, centered=comp.frame_style == "centered", kaldi_shift=comp.kaldi_shift,
+                    include_energy=comp.includes_energy, use_power=bool(comp._power), use_log=bool(comp._log))
+                got = comp.compute_full_batch(sigs)
+                want = [orc.compute_full(x, p) for x in sigs]
+                kind = f"fused{comp.kernel_kind}" if comp.kernel_kind else "generic"
+                tol = dict(rtol=1e-4, atol=1e-5)
+            kinds[kind] = kinds.get(kind, 0) + 1
+            for n, y, w in zip(lens, got, want):
+                ok, msg = close(y, w, **tol)
+                if not ok:
+                    fails += 1
+                    print("FAIL", kind, "len", n, msg, json.dumps(cfg))
+                    break
+            if cfg["name"] == "stft" and comp.kernel_kind:
+                x = torch.from_numpy(sigs[6]).cuda()
+                y, _ = comp.compute_packed(x, [0], [lens[6]], generic=True)
+                ok, msg = close(y.cpu().numpy(), want[6], **tol)
+                if not ok:
+                    fails += 1
+                    print("FAIL generic-vs-oracle", msg, json.dumps(cfg))
+        except Exception:
+            fails += 1
+            print("ERROR", json.dumps(cfg))
+            traceback.print_exc()
+    print("configs by kernel:", json.dumps(kinds, sort_keys=True), "failures:", fails)
+    return 1 if fails else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
