@@ -115,6 +115,20 @@ int32_t upload(T **dst, const T *src, size_t count) {
   return PDS_OK;
 }
 
+// x[i] - c x[i-1] with the product rounded before the subtraction, as numpy evaluates the
+// reference's Preemphasize (pre.py:146): the samples a fused kernel frames are then bit-identical
+// to the separate pass.  (The multiply goes through asm so that -ffp-contract=fast cannot fuse it.)
+__device__ __forceinline__ float preemph_sample(float cur, float prev, float c) {
+  float t;
+  asm("v_mul_f32 %0, %1, %2" : "=v"(t) : "v"(c), "v"(prev));
+  return cur - t;
+}
+__device__ __forceinline__ double preemph_sample(double cur, double prev, double c) {
+  double t;
+  asm("v_mul_f64 %0, %1, %2" : "=v"(t) : "v"(c), "v"(prev));
+  return cur - t;
+}
+
 // symmetric reflection of index i into [0, n): numpy.pad(..., "symmetric") for any
 // pad width (reference compute.py:600)
 __device__ __forceinline__ int64_t reflect_index(int64_t i, int64_t n) {

@@ -276,11 +276,11 @@ __global__ __launch_bounds__(MAXWAVES * 64, MINW) void stft_wave_kernel(const Fa
                 0, __float_as_int(a[n1]), 0x121 /* row_ror:1 */, 0xf, 0xf, false));
             const float prev = r == 0 ? carry : rot;
             carry = rot;
-            a[n1] = fmaf(-p.preemph, prev, a[n1]);
+            a[n1] = preemph_sample(a[n1], prev, p.preemph);
           }
         } else {
 #pragma unroll
-          for (int n1 = 0; n1 < NROWS; ++n1) a[n1] = fmaf(-p.preemph, xp[n1 * N2 - 1], a[n1]);
+          for (int n1 = 0; n1 < NROWS; ++n1) a[n1] = preemph_sample(a[n1], xp[n1 * N2 - 1], p.preemph);
         }
       }
     } else {
@@ -297,7 +297,7 @@ __global__ __launch_bounds__(MAXWAVES * 64, MINW) void stft_wave_kernel(const Fa
             i = (int)reflect_index((int64_t)i, (int64_t)n);
           }
           v = x[i];
-          if (PRE && i > 0) v = fmaf(-p.preemph, x[i - 1], v);
+          if (PRE && i > 0) v = preemph_sample(v, x[i - 1], p.preemph);
         }
         tmp[n1 * 64 + lane] = v;
       }

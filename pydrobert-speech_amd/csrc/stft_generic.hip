@@ -57,7 +57,7 @@ __global__ __launch_bounds__(64 * FPB) void stft_generic_kernel(
   for (int j = lane; j < L; j += 64) {
     const int64_t i = reflect_index(start + j, n);
     T s = x[i];
-    if (preemph != (T)0 && i > 0) s -= preemph * x[i - 1];  // pre.py:146 before framing
+    if (preemph != (T)0 && i > 0) s = preemph_sample(s, x[i - 1], preemph);  // pre.py:146 before framing
     e += s * s;
     xw[j] = s * window[j];
   }

@@ -64,7 +64,13 @@ def draw_si(rng):
     return cfg
 
 
-def close(got, want, rtol, atol):
+def close(got, want, rtol, atol, is_log=False):
+    """|got - want| <= atol + rtol |want| per element -- or, for float32 arithmetic, inside the
+    round-off floor of the frame: a coefficient 40 dB and more below the frame's largest one
+    carries the FFT's float32 round-off (~1e-7 of the frame's amplitude) at full size, so its
+    own relative error exceeds 1e-4 although the frame as a whole is as accurate as float32
+    allows.  Such elements pass when their error is below 1e-6 of the frame's largest coefficient
+    (in the linear domain for log features)."""
     got, want = np.asarray(got, np.float64), np.asarray(want, np.float64)
     if got.shape != want.shape:
         return False, f"shape {got.shape} vs {want.shape}"
@@ -73,9 +79,12 @@ def close(got, want, rtol, atol):
     nan = np.isnan(want)
     if (np.isnan(got) != nan).any():
         return False, "nan pattern"
-    scale = np.maximum(np.abs(want), np.abs(want[~nan]).max() * 1e-3 if (~nan).any() else 1.0)
     err = np.abs(got - want)
-    bad = (err > atol + rtol * scale) & ~nan
+    bad = (err > atol + rtol * np.abs(want)) & ~nan
+    if bad.any() and rtol > 1e-8 and want.ndim == 2:
+        lin_got, lin_want = (np.exp(got), np.exp(want)) if is_log else (got, want)
+        frame_peak = np.nanmax(np.abs(lin_want), axis=1, keepdims=True)
+        bad &= np.abs(lin_got - lin_want) > 1e-6 * frame_peak
     return (not bad.any()), f"{int(bad.sum())} bad, max err {np.nanmax(err):.3g}"
 
 
@@ -115,21 +124,34 @@ def main():
                     starts=list(comp._filt_start_idxs), taps=[np.asarray(t) for t in comp._truncated_filts],
                     is_real=comp.bank.is_real, centered=comp.frame_style == "centered", kaldi_shift=comp.kaldi_shift,
                     include_energy=comp.includes_energy, use_power=bool(comp._power), use_log=bool(comp._log))
-                got = comp.compute_full_batch(sigs)
-                want = [orc.compute_full(x, p) for x in sigs]
-                kind = f"fused{comp.kernel_kind}" if comp.kernel_kind else "generic"
-                tol = dict(rtol=1e-4, atol=1e-5)
+                mode = rng.random()
+                if mode < 0.2:    # float64 signals: float64 arithmetic on the direct-DFT kernel
+                    sigs = [x.astype("f8") for x in sigs]
+                    got = comp.compute_full_batch(sigs)
+                    want = [orc.compute_full(x, p) for x in sigs]
+                    kind, tol = "f64", dict(rtol=1e-9, atol=1e-9)
+                elif mode < 0.45:  # pre-emphasis fused into the frame loads
+                    coeff = float(rng.choice([0.5, 0.9, 0.97]))
+                    got = comp.compute_full_batch(sigs, preemphasis=coeff)
+                    want = [orc.compute_full(orc.preemphasize(x, coeff), p) for x in sigs]
+                    kind = f"pre+fused{comp.kernel_kind}" if comp.kernel_kind else "pre+generic"
+                    tol = dict(rtol=1e-4, atol=1e-5)
+                else:
+                    got = comp.compute_full_batch(sigs)
+                    want = [orc.compute_full(x, p) for x in sigs]
+                    kind = f"fused{comp.kernel_kind}" if comp.kernel_kind else "generic"
+                    tol = dict(rtol=1e-4, atol=1e-5)
             kinds[kind] = kinds.get(kind, 0) + 1
             for n, y, w in zip(lens, got, want):
-                ok, msg = close(y, w, **tol)
+                ok, msg = close(y, w, is_log=bool(comp._log), **tol)
                 if not ok:
                     fails += 1
                     print("FAIL", kind, "len", n, msg, json.dumps(cfg))
                     break
-            if cfg["name"] == "stft" and comp.kernel_kind:
+            if cfg["name"] == "stft" and comp.kernel_kind and kind.startswith("fused"):
                 x = torch.from_numpy(sigs[6]).cuda()
                 y, _ = comp.compute_packed(x, [0], [lens[6]], generic=True)
-                ok, msg = close(y.cpu().numpy(), want[6], **tol)
+                ok, msg = close(y.cpu().numpy(), want[6], is_log=bool(comp._log), **tol)
                 if not ok:
                     fails += 1
                     print("FAIL generic-vs-oracle", msg, json.dumps(cfg))
