@@ -198,7 +198,14 @@ __global__ __launch_bounds__(MAXWAVES * 64, MINW) void stft_wave_kernel(const Fa
   // chunks) pair -- scalar instructions compete with vector ones for issue slots, so the
   // bookkeeping per item is kept to a handful of them.
   int b = 0;
-  int chunk = blockIdx.x * p.waves + wave;
+  // Workgroups are handed to the 8 XCDs round-robin (workgroup i runs on XCD i % 8, each with its
+  // own L2): renumber them so that an XCD's workgroups take neighbouring chunks and the samples
+  // two neighbours share (L - S per frame) are fetched into one L2 instead of two.
+  int wg = blockIdx.x;
+#ifndef PDS_NO_XCD_MAP
+  if ((gridDim.x & 7) == 0) wg = (wg & 7) * (gridDim.x >> 3) + (wg >> 3);
+#endif
+  int chunk = wg * p.waves + wave;
   while (chunk >= p.chunks_per_utt && b < p.num_utts) {  // once per kernel
     chunk -= p.chunks_per_utt;
     ++b;
