@@ -88,6 +88,40 @@ def close(got, want, rtol, atol, is_log=False):
     return (not bad.any()), f"{int(bad.sum())} bad, max err {np.nanmax(err):.3g}"
 
 
+def fuzz_post(rng, rounds):
+    """Deltas / CMVN / Stack over packed ragged batches against per-utterance numpy restatements"""
+    import torch
+
+    from pydrobert_speech_amd.post import Deltas, Stack, Standardize
+
+    fails = 0
+    for _ in range(rounds):
+        F = int(rng.integers(1, 130))
+        lens = [int(v) for v in rng.integers(2, 400, size=int(rng.integers(1, 9)))]
+        rows = np.concatenate([[0], np.cumsum(lens)])
+        feats = (rng.standard_normal((rows[-1], F)) * rng.uniform(0.1, 50) + rng.uniform(-5, 5)).astype("f4")
+        d = torch.from_numpy(feats).cuda()
+        K, W = int(rng.integers(1, 4)), int(rng.integers(1, 5))
+        got = Deltas(K, context_window=W).apply_rows(d, rows).cpu().numpy()
+        nv = int(rng.integers(1, 6))
+        pad = [None, "constant", "edge"][int(rng.integers(0, 3))]
+        st = Stack(nv, pad_mode=pad)
+        sgot, srows = st.apply_rows(d, rows)
+        sgot = sgot.cpu().numpy()
+        cgot = Standardize(norm_var=bool(rng.random() < 0.7))
+        cres = cgot.apply_rows(d, rows).cpu().numpy()
+        for b in range(len(lens)):
+            x = feats[rows[b] : rows[b + 1]]
+            ok = np.array_equal(got[rows[b] : rows[b + 1]], orc.deltas(x, axis=0, num_deltas=K, context_window=W, target_axis=1))
+            ok &= np.array_equal(sgot[srows[b] : srows[b + 1]], st.apply(x, axis=1))
+            ok &= np.allclose(cres[rows[b] : rows[b + 1]], orc.cmvn_local(x, axis=-1, norm_var=cgot._norm_var), rtol=1e-9, atol=1e-9)
+            if not ok:
+                fails += 1
+                print("FAIL post", dict(F=F, T=lens[b], K=K, W=W, nv=nv, pad=pad))
+                break
+    return fails
+
+
 def main():
     import torch
 
@@ -159,6 +193,7 @@ def main():
             fails += 1
             print("ERROR", json.dumps(cfg))
             traceback.print_exc()
+    fails += fuzz_post(rng, max(1, count // 10))
     print("configs by kernel:", json.dumps(kinds, sort_keys=True), "failures:", fails)
     return 1 if fails else 0
 
