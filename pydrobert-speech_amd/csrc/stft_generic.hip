@@ -24,10 +24,12 @@ struct Tw;
 template <>
 struct Tw<float> {
   using type = float2;
+  typedef float quad __attribute__((ext_vector_type(4)));  // 16-byte LDS read
 };
 template <>
 struct Tw<double> {
   using type = double2;
+  typedef double quad __attribute__((ext_vector_type(2)));
 };
 
 template <typename T>
@@ -56,7 +58,8 @@ __global__ __launch_bounds__(64 * FPB) void stft_generic_kernel(
   const T *x = sig + offsets[b];
   constexpr int J = 16;                   // samples per block of the dot product
   const int Lp = (L + J - 1) / J * J;     // frame padded with zeros to whole blocks
-  T *xw = reinterpret_cast<T *>(smem_raw) + (size_t)wave * (Lp + num_bins);
+  // (a wave's area is a multiple of 16 bytes long, so the frame can be read 16 bytes at a time)
+  T *xw = reinterpret_cast<T *>(smem_raw) + (size_t)wave * (Lp + ((num_bins + 3) & ~3));
   T *pw = xw + Lp;
 
   // frame -> LDS (windowed); energy on the un-windowed samples (compute.py:392-393)
@@ -87,11 +90,16 @@ __global__ __launch_bounds__(64 * FPB) void stft_generic_kernel(
     T re = 0, im = 0;
     for (int j0 = 0; j0 < Lp; j0 += J) {
       T a = 0, bs = 0;  // sum v cos, sum v sin over the block, relative to its first sample
+      using Quad = typename Tw<T>::quad;
+      constexpr int QN = 16 / sizeof(T);
 #pragma unroll
-      for (int j = 0; j < J; ++j) {
-        const T v = xw[j0 + j];
-        a += v * cj[j];
-        bs += v * sj[j];
+      for (int j = 0; j < J; j += QN) {
+        const Quad v = *reinterpret_cast<const Quad *>(xw + j0 + j);
+#pragma unroll
+        for (int u = 0; u < QN; ++u) {
+          a += v[u] * cj[j + u];
+          bs += v[u] * sj[j + u];
+        }
       }
       re += c0 * a - s0 * bs;
       im -= s0 * a + c0 * bs;
@@ -141,7 +149,7 @@ static int32_t launch_one(const pds_stft_plan *p, const BatchArgs &a, const T *w
 template <typename T>
 static int32_t launch_generic(const pds_stft_plan *p, const BatchArgs &a, const T *window,
                               const typename Tw<T>::type *tw, const T *val) {
-  const size_t per_frame = (size_t)((p->d.frame_length + 15) / 16 * 16 + p->num_bins) * sizeof(T);
+  const size_t per_frame = (size_t)((p->d.frame_length + 15) / 16 * 16 + ((p->num_bins + 3) & ~3)) * sizeof(T);
   const size_t budget = 150 * 1024;
   if (4 * per_frame <= budget) return launch_one<T, 4>(p, a, window, tw, val, 4 * per_frame);
   if (per_frame <= budget) return launch_one<T, 1>(p, a, window, tw, val, per_frame);
