@@ -140,6 +140,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--preroll-ms", type=float, default=60.0,
+                    help="untimed launches before the warm-up, for this many milliseconds: the GPU leaves "
+                         "its idle clock state only after ~40 ms of continuous work (tools/clock_ramp.py: "
+                         "0.38 ms per step at first, 0.32 ms from step ~100 on); 0 disables")
     ap.add_argument("--workload", default=DEFAULT_WORKLOAD, choices=sorted(WORKLOADS))
     ap.add_argument("--batch", type=int, default=None, help="utterances per GPU (default: workload's)")
     ap.add_argument("--ragged", action="store_true",
@@ -236,19 +240,30 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
+    # pre-roll (not part of W or K): bring the clocks up so that the timed region measures the
+    # steady state whatever K is
+    preroll = 0
+    if args.preroll_ms > 0:
+        t_end = time.perf_counter() + 1e-3 * args.preroll_ms
+        while time.perf_counter() < t_end:
+            for _ in range(10):
+                step()
+            torch.cuda.synchronize(dev)
+            preroll += 10
     for _ in range(args.warmup):
         step()
     barrier()
     # timed region: exactly K steps, events on the launch stream give the kernel time
-    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    # (one event per step boundary: step i runs between marks i and i + 1)
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     t0 = time.perf_counter()
-    for a, b in evs:
-        a.record()
+    marks[0].record()
+    for i in range(args.steps):
         step()
-        b.record()
+        marks[i + 1].record()
     barrier()
     elapsed = time.perf_counter() - t0
-    kernel_ms = [a.elapsed_time(b) for a, b in evs]
+    kernel_ms = [marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps)]
     if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -307,6 +322,7 @@ def main():
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
+            "preroll_steps": preroll,
             "ms_per_step": 1e3 * elapsed / args.steps,
             "higher_is_better": True,
             "scaling": "weak",

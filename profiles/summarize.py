@@ -19,6 +19,19 @@ for r in stats[:4]:
         r["Name"][:70], r["Calls"], r["AverageNs"], r["MinNs"], r["MaxNs"], r["Percentage"]))
 kern = next(r for r in stats if "stft_" in r["Name"])
 avg_s = float(kern["AverageNs"]) * 1e-9
+# bench.py times its LAST `steps` launches (after the clock pre-roll and the warm-up): the same
+# window from the kernel trace is the duration its roofline line must agree with
+steps = int(sys.argv[3]) if len(sys.argv) > 3 else 100
+trace_path = os.path.join(d, "stats", "stats_kernel_trace.csv")
+if os.path.exists(trace_path):
+    rows = [r for r in csv.DictReader(open(trace_path)) if "stft_" in r["Kernel_Name"]]
+    rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+    last = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in rows[-steps:]]
+    first = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in rows[:40]]
+    lines.append("  kernel trace: %d launches; first 40 mean %.1f us (clocks ramping), last %d (the timed region) "
+                 "mean %.1f us min %.1f us" % (len(rows), sum(first) / len(first) / 1e3, len(last),
+                                              sum(last) / len(last) / 1e3, min(last) / 1e3))
+    avg_s = sum(last) / len(last) * 1e-9
 for sub in ("pmc_fetch", "pmc_write", "pmc_sq1", "pmc_sq2", "pmc_misc"):
     path = os.path.join(d, sub, "pmc_counter_collection.csv")
     if not os.path.exists(path):
