@@ -44,7 +44,7 @@ namespace pds {
 #define PDS_ABLATE 0
 #endif
 #ifndef PDS_FILTER_UNROLL
-#define PDS_FILTER_UNROLL 1
+#define PDS_FILTER_UNROLL 2
 #endif
 __device__ __forceinline__ void keep_alive(float v) { asm volatile("" ::"v"(v)); }
 
