@@ -524,10 +524,11 @@ __global__ __launch_bounds__(MAXWAVES * 64, MINW) void stft_wave_kernel(const Fa
       const int woff = slot_woff_ + r * (len + 4);  // + 4: conflict-free row skew
       float acc0 = 0.0f, acc1 = 0.0f, acc2 = 0.0f, acc3 = 0.0f;
       const float4 *wrow = reinterpret_cast<const float4 *>((ELL_LDS ? ellw_lds : p.ell_w) + woff);
-#pragma unroll PDS_FILTER_UNROLL
-      for (int t4 = 0; t4 < ((PDS_ABLATE & 32) ? 2 : len / 4); t4 += 2) {
-        const float4 w0 = wrow[t4], w1 = wrow[t4 + 1];
-        const float4 p0 = prow[t4], p1 = prow[t4 + 1];
+      // 8 bins per step, two steps per pass of the loop (8 LDS reads in flight per 16
+      // multiply-adds); the trip count is a shift of the row length, which is a multiple of 8
+      auto step = [&]() {
+        const float4 w0 = wrow[0], w1 = wrow[1];
+        const float4 p0 = prow[0], p1 = prow[1];
         acc0 = fmaf(w0.x, p0.x, acc0);
         acc1 = fmaf(w0.y, p0.y, acc1);
         acc2 = fmaf(w0.z, p0.z, acc2);
@@ -536,7 +537,16 @@ __global__ __launch_bounds__(MAXWAVES * 64, MINW) void stft_wave_kernel(const Fa
         acc1 = fmaf(w1.y, p1.y, acc1);
         acc2 = fmaf(w1.z, p1.z, acc2);
         acc3 = fmaf(w1.w, p1.w, acc3);
+        wrow += 2;
+        prow += 2;
+      };
+      const unsigned steps = (PDS_ABLATE & 32) ? 1u : (unsigned)len >> 3;
+#pragma unroll 1
+      for (unsigned i = steps >> 1; i != 0; --i) {
+        step();
+        step();
       }
+      if (steps & 1u) step();
       float acc = (acc0 + acc1) + (acc2 + acc3);
       // max(val, floor) as Python evaluates it: a NaN stays a NaN (compute.py:459)
       if (p.use_log) acc = fast_log(p.log_floor > acc ? p.log_floor : acc);
