@@ -14,7 +14,9 @@ import pytest
 from pydrobert_speech_amd.alias import alias_factory_subclass_from_arg
 from pydrobert_speech_amd.compute import FrameComputer, frame_by_frame_calculation
 from oracle import stft_oracle as orc
-from tests.conftest import assert_features_close, config_names, oracle_params
+import os
+
+from tests.conftest import GOLDEN, assert_features_close, config_names, oracle_params
 
 pytestmark = pytest.mark.gpu
 CONFIGS = config_names()
@@ -296,3 +298,19 @@ def test_float64_signals_can_opt_into_float32_arithmetic(computers, golden_stft,
     assert fast.dtype == np.float64 and fast.shape == want.shape
     assert_features_close(fast, want, **F32)
     assert np.abs(fast - want).max() > 1e-9  # it really was float32 arithmetic
+
+
+@pytest.mark.parametrize("name", ["c1_kaldi_fbank", "c2_tri_mel40", "v_tri_analytic_nolog", "v_gabor_nopad_mag"])
+def test_streaming_random_chunkings_match_reference_call_by_call(name, computers, master_signal):
+    # tests/golden/make_golden_stream.py: eight lengths (one sample .. 4000) x random cut points;
+    # every compute_chunk / finalize call must return as many frames as the reference's did
+    with np.load(os.path.join(GOLDEN, "stream_random.npz")) as z:
+        g = {k: z[k] for k in z.files if k.startswith(name + "/")}
+    comp = computers[name]
+    for case in range(8):
+        n = int(g[f"{name}/{case}/n"])
+        x = master_signal[50 : 50 + n].astype("f4")
+        pieces = np.split(x, g[f"{name}/{case}/cuts"])
+        outs = [comp.compute_chunk(p) for p in pieces] + [comp.finalize()]
+        assert [len(o) for o in outs] == g[f"{name}/{case}/counts"].tolist(), (name, case)
+        assert_features_close(np.concatenate(outs), g[f"{name}/{case}/feats"], what=(name, case), **F32)
