@@ -151,3 +151,19 @@ def test_long_frame_shift_takes_several_passes():
         close(comp.compute_full(x), so.compute_full(x, p), **F32)
     x8 = (rng.standard_normal(12000) * 1000).astype("f8")
     close(comp.compute_full(x8), so.compute_full(x8, p), rtol=1e-9, atol=1e-9)
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_streaming_random_chunkings_call_by_call(name):
+    # tests/golden/make_golden_stream.py: six lengths x random cut points per configuration
+    with np.load(os.path.join(GOLDEN, "si_stream_random.npz")) as z:
+        g = {k: z[k] for k in z.files if k.startswith(name + "/")}
+    with np.load(os.path.join(GOLDEN, "si.npz")) as z:
+        master = z["master"]
+    comp = build(name)
+    for case in range(6):
+        n = int(g[f"{name}/{case}/n"])
+        x = master[7 : 7 + n].astype("f4")
+        outs = [comp.compute_chunk(p) for p in np.split(x, g[f"{name}/{case}/cuts"])] + [comp.finalize()]
+        assert [len(o) for o in outs] == g[f"{name}/{case}/counts"].tolist(), (name, case)
+        close(np.concatenate(outs), g[f"{name}/{case}/feats"], **F32)
