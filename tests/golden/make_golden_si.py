@@ -37,6 +37,9 @@ CONFIGS = {
     "s4_gabor_8k_short": {"name": "si", "bank": {"name": "gabor", "scaling_function": "bark", "num_filts": 8,
                           "sampling_rate": 8000}, "pad_to_nearest_power_of_two": False,
                           "window_function": "hamming", "use_power": True},
+    # real bank sampled in frequency (impulse responses by inverse DFT), supports of ~7000 taps:
+    # beyond the FFT form's 1024-point transforms, so float32 takes the direct kernel too
+    "s6_fbank_long": {"name": "si", "bank": {"name": "fbank", "num_filts": 3}, "use_power": True},
     # causal style forced on a zero-phase bank
     "s5_gabor_causal": {"name": "si", "bank": {"name": "gabor", "scaling_function": "mel", "num_filts": 5},
                         "frame_style": "causal", "frame_shift_ms": 12.5},
