@@ -180,7 +180,18 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+            # started without a launcher: become one (a child process -- this process has not touched
+            # the GPU -- whose exit code is passed on)
+            import socket
+            import subprocess
+
+            with socket.socket() as sock:
+                sock.bind(("127.0.0.1", 0))
+                port = sock.getsockname()[1]
+            os.dup2(saved_stdout, 1)  # the rank-0 child prints the JSON line on the real stdout
+            cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+                   "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+            sys.exit(subprocess.run(cmd).returncode)
         args.gpus = world
 
     import numpy as np
