@@ -72,6 +72,12 @@ WORKLOADS = {
          "include_energy": True, "use_power": True},
         160000, 64, None,
     ),
+    # longer supports (48 kHz gammatone bank, ~1300 taps): the 2048-point form of the same kernel
+    "si_gammatone40_48k_b32x10s": (
+        {"name": "si", "bank": {"name": "gammatone", "scaling_function": "mel", "num_filts": 40,
+                                "sampling_rate": 48000}, "use_power": True},
+        480000, 32, None,
+    ),
 }
 DEFAULT_WORKLOAD = "fbank40_16k_25_10_b1024x10s"
 
@@ -372,7 +378,8 @@ def main():
                 "frames_per_gpu_per_step": frames, "num_coeffs": comp.num_coeffs, "post": post,
                 "frame_length": comp.frame_length, "frame_shift": comp.frame_shift,
                 "dft_size": comp.dft_size, "parallelism": f"utterance-sharded x{world}",
-                "kernel": ("si-direct-fir" if args.generic else "si-overlap-save-fft1024") if is_si else
+                "kernel": ("si-direct-fir" if (args.generic or not comp.fft_size) else
+                           f"si-overlap-save-fft{comp.fft_size}") if is_si else
                           "generic-direct-dft" if (args.generic or not comp.kernel_kind) else "fused-fft",
             },
             "roofline": {

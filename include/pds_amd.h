@@ -251,11 +251,15 @@ void pds_si_plan_destroy(pds_si_plan *plan);
  * compute.py:781-850); `start` is the stream position of the first integrated sample
  * (skipped samples minus virtual leading zeros, compute.py:859-865) -- a caller that streams
  * passes start + t0 * S to continue at frame t0. */
-/* float32 has two forms: overlap-save with 1024-point FFTs (filter supports up to 1024 - S taps)
+/* float32 has two forms: overlap-save with 1024- or 2048-point FFTs (filter supports up to 2048 - S taps)
  * when d_scratch points to pds_si_scratch_len(plan, B, max_frames) floats of device memory, and
  * direct time-domain filtering when d_scratch is NULL (or the supports are too long: the length
  * is then 0).  float64 signals always take the direct form. */
 int64_t pds_si_scratch_len(const pds_si_plan *plan, int32_t B, int64_t max_frames);
+/* transform size of the plan's FFT form: 1024, 2048 (supports up to 2048 - S taps; also chosen
+ * for shorter supports when it wastes less of a transform on the overlap), or 0 when the supports
+ * are too long for it and float32 takes the direct form as well */
+int32_t pds_si_plan_fft_size(const pds_si_plan *plan);
 int32_t pds_si_batch_f32(const pds_si_plan *plan, const float *d_signal, const int64_t *d_offsets,
                          const int64_t *d_lengths, const int64_t *d_nframes,
                          const int64_t *d_row_off, int32_t B, int64_t max_frames, int64_t start,

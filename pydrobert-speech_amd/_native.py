@@ -120,6 +120,7 @@ SIGNATURES = {
     "pds_si_plan_create": (c_int32, [POINTER(SiDesc), c_void_p, c_void_p, POINTER(c_void_p)]),
     "pds_si_plan_destroy": (None, [c_void_p]),
     "pds_si_scratch_len": (c_int64, [c_void_p, c_int32, c_int64]),
+    "pds_si_plan_fft_size": (c_int32, [c_void_p]),
     "pds_si_batch_f32": (c_int32, _SI_BATCH_ARGS[:9] + [c_void_p] + _SI_BATCH_ARGS[9:]),
     "pds_si_batch_f64": (c_int32, _SI_BATCH_ARGS),
     "pds_cmvn_scratch_len": (c_int64, [c_int64, c_int64]),

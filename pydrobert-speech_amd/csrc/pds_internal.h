@@ -55,9 +55,11 @@ struct pds_stft_plan {
 // Tables of the FFT form of the short-integration kernel (si_fft.hip); owned by the plan.
 namespace pds {
 struct SiFftTables {
-  int blocks = 0;              // shift-sized blocks each 1024-point transform yields (0: not available)
-  float2 *d_spectra = nullptr;  // [C][1024] filter spectra / 1024
+  int blocks = 0;              // shift-sized blocks each transform yields (0: form not available)
+  bool big = false;            // 2048-point transforms (one per wavefront) instead of 1024-point
+  float2 *d_spectra = nullptr;  // [C][NT] filter spectra / NT
   float2 *d_twiddle = nullptr;  // [32][32] W_1024^(q * lane), row q
+  float2 *d_twiddle2k = nullptr;  // [32][32] W_2048^(32 q + lane), row q
   int num_cus = 0;
 };
 }  // namespace pds

@@ -244,6 +244,11 @@ void pds_si_plan_destroy(pds_si_plan *plan) {
   delete plan;
 }
 
+int32_t pds_si_plan_fft_size(const pds_si_plan *plan) {
+  if (!plan || plan->fft.blocks == 0) return 0;
+  return plan->fft.big ? 2048 : 1024;
+}
+
 int64_t pds_si_scratch_len(const pds_si_plan *plan, int32_t B, int64_t max_frames) {
   return pds::si_fft_scratch_len(plan, B, max_frames);
 }

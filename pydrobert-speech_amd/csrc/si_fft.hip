@@ -46,6 +46,7 @@ struct SiFftArgs {
   float *scratch;
   int64_t blocks_per_utt;   // scratch rows (shift-sized blocks) reserved per utterance
   const float2 *spectra, *twiddle;
+  const float2 *twiddle2k;  // [32][32] W_2048^(32 q + l), row q (2048-point form only)
   const float *window;
   int64_t start;
   int S, C, blocks, use_power;
@@ -82,7 +83,17 @@ __device__ __forceinline__ void fft1024(float (&zr)[kL], float (&zi)[kL], float2
   inl::CFFT<kL, 1>::run(ar, ai, zr, zi);
 }
 
+// BIG: one 2048-point transform per wavefront instead of two 1024-point ones -- radix 2 on top of
+// the half-wave routine.  Time layout: sample n in half n & 1, lane (n >> 1) & 31, register n >> 6
+// (each half holds a decimated sequence); frequency layout: bin k in half k >> 10, lane k & 31,
+// register (k >> 5) & 31.  Forward: FFT-1024 per half, then E +- W^j O between the halves; the
+// inverse runs the mirror image (sum / twiddled difference between the halves, then FFT-1024 per
+// half), so both directions cost one exchange between the halves and one twiddle multiply more
+// than the 1024-point form.  It serves filter supports up to 2048 - S taps and is also chosen for
+// shorter ones when it wastes less of each transform on the overlap.
+template <bool BIG>
 __global__ __launch_bounds__(kWaves * 64, 1) void si_fft_kernel(const SiFftArgs p) {
+  constexpr int NT = BIG ? 2 * kN : kN;
   extern __shared__ __attribute__((aligned(16))) unsigned char si_fft_smem[];
   float2 *xch_all = reinterpret_cast<float2 *>(si_fft_smem);          // [2 kWaves][32][33]
   float *wexp = reinterpret_cast<float *>(xch_all + 2 * kWaves * kL * kRowStride);  // [2][V]: window halves, periodic
@@ -92,55 +103,78 @@ __global__ __launch_bounds__(kWaves * 64, 1) void si_fft_kernel(const SiFftArgs 
     wexp[V + i] = p.window[p.S + i % p.S];
   }
   __syncthreads();
-  const int half = threadIdx.x >> 5;       // 0 .. 2 kWaves - 1: one transform each
+  const int half = threadIdx.x >> 5;       // 0 .. 2 kWaves - 1: one FFT-1024 each
   const int l = threadIdx.x & 31;
+  const int hw = half & 1;                 // half of the wavefront
+  const int lt = BIG ? (threadIdx.x & 63) : l;  // lane within the transform
   float2 *xch = xch_all + half * kL * kRowStride;
   const int b = blockIdx.y;
   const int64_t Tb = p.nframes[b];
   const int64_t num_dft = (Tb + 1 + p.blocks - 1) / p.blocks;  // frames need blocks 0 .. Tb
-  const int64_t d = (int64_t)blockIdx.x * (2 * kWaves) + half;
+  const int64_t d = BIG ? (int64_t)blockIdx.x * kWaves + (half >> 1) : (int64_t)blockIdx.x * (2 * kWaves) + half;
   // (both halves of a wave take the same branch or wave-level code below would deadlock: the
   // half without work still walks through with a zero signal and stores nothing)
   const bool has_work = d < num_dft;
   if (__builtin_amdgcn_readfirstlane((int)__any(has_work)) == 0) return;
   const int64_t n = p.lengths[b];
   const float *x = p.sig + p.offsets[b];
-  // element m of the stretch is signal sample d V + start - (1024 - V) + m: the last V outputs of
+  // element m of the stretch is signal sample d V + start - (NT - V) + m: the last V outputs of
   // the circular convolution are the filtered samples d V .. d V + V - 1
-  const int64_t s0 = d * V + p.start - (kN - V);
-  const int first_valid = kN - V;
+  const int64_t s0 = d * V + p.start - (NT - V);
+  const int first_valid = NT - V;
+  // sample held in register q (time layout) and bin held in register q (frequency layout)
+  auto sample_of = [&](int q) { return BIG ? 64 * q + 2 * l + hw : kL * q + l; };
+  auto bin_of = [&](int q) { return BIG ? kN * hw + kL * q + l : kL * q + l; };
   float twr[kL], twi[kL], wa[kL], wb[kL];  // loop invariants of the lane (see fft1024)
+  float t2r[BIG ? kL : 1], t2i[BIG ? kL : 1];  // W_2048^(32 q + l)
 #pragma unroll
   for (int q = 0; q < kL; ++q) {
     const float2 t = p.twiddle[q * kL + l];
     twr[q] = t.x;
     twi[q] = t.y;
-    const int m = q * kL + l - first_valid;  // position inside the V filtered samples
+    if constexpr (BIG) {
+      const float2 t2 = p.twiddle2k[q * kL + l];
+      t2r[q] = t2.x;
+      t2i[q] = t2.y;
+    }
+    const int m = sample_of(q) - first_valid;  // position inside the V filtered samples
     wa[q] = m >= 0 ? wexp[m] : 0.0f;
     wb[q] = m >= 0 ? wexp[V + m] : 0.0f;
   }
   float zr[kL], zi[kL];
 #pragma unroll
   for (int q = 0; q < kL; ++q) {
-    const int64_t idx = s0 + q * kL + l;
+    const int64_t idx = s0 + sample_of(q);
     zr[q] = (has_work && idx >= 0 && idx < n) ? x[idx] : 0.0f;
     zi[q] = 0.0f;
   }
   fft1024(zr, zi, xch, twr, twi, l);
+  if constexpr (BIG) {
+    // X[j] = E[j] + W^j O[j] (lower half), X[j + 1024] = E[j] - W^j O[j] (upper half)
+#pragma unroll
+    for (int q = 0; q < kL; ++q) {
+      const float ur = hw ? zr[q] * t2r[q] - zi[q] * t2i[q] : zr[q];
+      const float ui = hw ? zr[q] * t2i[q] + zi[q] * t2r[q] : zi[q];
+      const float pr = __shfl_xor(ur, 32, 64), pi = __shfl_xor(ui, 32, 64);
+      zr[q] = hw ? pr - ur : ur + pr;
+      zi[q] = hw ? pi - ui : ui + pi;
+    }
+  }
   float xr[kL], xi[kL];  // the stretch's spectrum stays in the lane's registers for every filter
 #pragma unroll
   for (int q = 0; q < kL; ++q) {
     xr[q] = zr[q];
     xi[q] = zi[q];
   }
-  float *zw = reinterpret_cast<float *>(xch);  // [2][V] after the last transposition of a filter
+  // [2][V] after the last transposition of a filter (2048-point form: the wave's two areas)
+  float *zw = reinterpret_cast<float *>(BIG ? xch_all + (half & ~1) * kL * kRowStride : xch);
   float *srow = p.scratch + ((int64_t)b * p.blocks_per_utt + d * p.blocks) * p.C * 2;
   // the filter's spectrum is fetched one filter ahead: 32 loads in flight under the transform of
   // the filter before instead of 32 round trips in front of this one
   float hr[kL], hi[kL];
 #pragma unroll
   for (int q = 0; q < kL; ++q) {
-    const float2 hs = p.spectra[q * kL + l];
+    const float2 hs = p.spectra[bin_of(q)];
     hr[q] = hs.x;
     hi[q] = hs.y;
   }
@@ -152,12 +186,22 @@ __global__ __launch_bounds__(kWaves * 64, 1) void si_fft_kernel(const SiFftArgs 
       zi[q] = -(xr[q] * hi[q] + xi[q] * hr[q]);
     }
     {
-      const float2 *h = p.spectra + (size_t)(c + 1 < p.C ? c + 1 : c) * kN;
+      const float2 *h = p.spectra + (size_t)(c + 1 < p.C ? c + 1 : c) * NT;
 #pragma unroll
       for (int q = 0; q < kL; ++q) {
-        const float2 hs = h[q * kL + l];
+        const float2 hs = h[bin_of(q)];
         hr[q] = hs.x;
         hi[q] = hs.y;
+      }
+    }
+    if constexpr (BIG) {
+      // a[j] = Z[j] + Z[j + 1024] (lower half), b[j] = (Z[j] - Z[j + 1024]) W^j (upper half)
+#pragma unroll
+      for (int q = 0; q < kL; ++q) {
+        const float pr = __shfl_xor(zr[q], 32, 64), pi = __shfl_xor(zi[q], 32, 64);
+        const float dr = pr - zr[q], di = pi - zi[q];
+        zr[q] = hw ? dr * t2r[q] - di * t2i[q] : zr[q] + pr;
+        zi[q] = hw ? dr * t2i[q] + di * t2r[q] : zi[q] + pi;
       }
     }
     fft1024(zr, zi, xch, twr, twi, l);
@@ -165,7 +209,7 @@ __global__ __launch_bounds__(kWaves * 64, 1) void si_fft_kernel(const SiFftArgs 
     // the alias-free part go to a dump slot behind the two arrays (no branches in this loop)
 #pragma unroll
     for (int q = 0; q < kL; ++q) {
-      const int m = q * kL + l - first_valid;  // position inside the V filtered samples
+      const int m = sample_of(q) - first_valid;  // position inside the V filtered samples
       float z = zr[q] * zr[q] + zi[q] * zi[q];
       if (!p.use_power) z = __builtin_amdgcn_sqrtf(z);
       zw[m >= 0 ? m : 2 * V] = z * wa[q];
@@ -181,7 +225,7 @@ __global__ __launch_bounds__(kWaves * 64, 1) void si_fft_kernel(const SiFftArgs 
       part[task] = 0.0f;
       if (task < 2 * p.blocks) {
         const float *src = zw + (task & 1) * V + (task >> 1) * p.S;
-        for (int m = l; m < p.S; m += kL) part[task] += src[m];
+        for (int m = lt; m < p.S; m += (BIG ? 64 : kL)) part[task] += src[m];
       }
     }
 #pragma unroll
@@ -194,10 +238,13 @@ __global__ __launch_bounds__(kWaves * 64, 1) void si_fft_kernel(const SiFftArgs 
       part[task] = v;
     }
 #pragma unroll
-    for (int task = 0; task < 2 * kMaxBlocks; ++task) part[task] += __shfl_xor(part[task], 16, 64);
+    for (int task = 0; task < 2 * kMaxBlocks; ++task) {
+      part[task] += __shfl_xor(part[task], 16, 64);
+      if constexpr (BIG) part[task] += __shfl_xor(part[task], 32, 64);
+    }
 #pragma unroll
     for (int task = 0; task < 2 * kMaxBlocks; ++task)
-      if (task < 2 * p.blocks && l == 0 && has_work)
+      if (task < 2 * p.blocks && lt == 0 && has_work)
         srow[((int64_t)(task >> 1) * p.C + c) * 2 + (task & 1)] = part[task];
     half_wave_sync();
   }
@@ -222,40 +269,56 @@ __global__ __launch_bounds__(256) void si_combine_kernel(const float *scratch, i
 
 }  // namespace
 
+// blocks of S filtered samples one NT-point transform yields for supports of M taps (0: none)
+static int blocks_for(int NT, int M, int S) {
+  if (M > NT) return 0;
+  const int blocks = std::min(kMaxBlocks, (NT - (M - 1)) / S);
+  // the transposition area(s) of the transform are reused for its 2 V + 1 weighted samples
+  const size_t area = (size_t)(NT / kN) * kL * kRowStride * sizeof(float2);
+  return (blocks >= 1 && ((size_t)2 * blocks * S + 1) * sizeof(float) <= area) ? blocks : 0;
+}
+
 int32_t si_fft_tables_create(pds_si_plan *plan, const double *taps) {
   SiFftTables &ft = plan->fft;
   ft.blocks = 0;
   const pds_si_desc &d = plan->d;
   const int M = d.max_support, S = d.frame_shift, C = d.num_coeffs;
-  // whole blocks in the alias-free part of a transform
-  const int blocks = std::min(kMaxBlocks, (kN - (M - 1)) / S);
-  if (M > kN || blocks < 1) return PDS_OK;  // supports too long for this form: direct kernel
-  // a half-wave's transposition area is reused for the V = blocks * S weighted samples, twice
-  if (((size_t)2 * blocks * S + 1) * sizeof(float) > (size_t)kL * kRowStride * sizeof(float2)) return PDS_OK;
-  std::vector<double> cs(kN), sn(kN);
-  for (int j = 0; j < kN; ++j) {
-    cs[j] = std::cos(2.0 * M_PI * j / kN);
-    sn[j] = std::sin(2.0 * M_PI * j / kN);
+  // 1024- or 2048-point transforms: whichever spends less of a transform on the overlap (the
+  // larger one pays ~20 % more per point for its extra radix-2 stage)
+  const int b1 = blocks_for(kN, M, S), b2 = blocks_for(2 * kN, M, S);
+  const double eff1 = (double)b1 * S / kN, eff2 = (double)b2 * S / (2 * kN) / 1.2;
+  if (b1 == 0 && b2 == 0) return PDS_OK;  // supports too long for this form: direct kernel
+  ft.big = eff2 > eff1;
+  const int NT = ft.big ? 2 * kN : kN, blocks = ft.big ? b2 : b1;
+  std::vector<double> cs(NT), sn(NT);
+  for (int j = 0; j < NT; ++j) {
+    cs[j] = std::cos(2.0 * M_PI * j / NT);
+    sn[j] = std::sin(2.0 * M_PI * j / NT);
   }
-  std::vector<float2> spectra((size_t)C * kN);
+  std::vector<float2> spectra((size_t)C * NT);
   const int w = d.taps_complex ? 2 : 1;
   for (int c = 0; c < C; ++c)
-    for (int k = 0; k < kN; ++k) {
+    for (int k = 0; k < NT; ++k) {
       double re = 0.0, im = 0.0;
-      for (int m = 0; m < M; ++m) {  // sum g[m] e^{-2 pi i k m / 1024}
+      for (int m = 0; m < M; ++m) {  // sum g[m] e^{-2 pi i k m / NT}
         const double gr = taps[((size_t)c * M + m) * w], gi = w == 2 ? taps[((size_t)c * M + m) * 2 + 1] : 0.0;
-        const int j = (int)(((int64_t)k * m) % kN);
+        const int j = (int)(((int64_t)k * m) % NT);
         re += gr * cs[j] + gi * sn[j];
         im += gi * cs[j] - gr * sn[j];
       }
-      spectra[(size_t)c * kN + k] = make_float2((float)(re / kN), (float)(im / kN));
+      spectra[(size_t)c * NT + k] = make_float2((float)(re / NT), (float)(im / NT));
     }
-  std::vector<float2> tw((size_t)kL * kL);
+  // W_1024^(q l) of the half-wave transform; W_2048^(32 q + l) of the radix-2 stage on top
+  std::vector<float2> tw((size_t)kL * kL), tw2((size_t)kL * kL);
   for (int q = 0; q < kL; ++q)
-    for (int l = 0; l < kL; ++l)
-      tw[(size_t)q * kL + l] = make_float2((float)cs[(q * l) % kN], (float)(-sn[(q * l) % kN]));
+    for (int l = 0; l < kL; ++l) {
+      const double a1 = -2.0 * M_PI * (q * l) / kN, a2 = -2.0 * M_PI * (kL * q + l) / (2 * kN);
+      tw[(size_t)q * kL + l] = make_float2((float)std::cos(a1), (float)std::sin(a1));
+      tw2[(size_t)q * kL + l] = make_float2((float)std::cos(a2), (float)std::sin(a2));
+    }
   int32_t rc = upload(&ft.d_spectra, spectra.data(), spectra.size());
   if (rc == PDS_OK) rc = upload(&ft.d_twiddle, tw.data(), tw.size());
+  if (rc == PDS_OK) rc = upload(&ft.d_twiddle2k, tw2.data(), tw2.size());
   if (rc != PDS_OK) return rc;
   hipDeviceProp_t prop;
   PDS_HIP(hipGetDeviceProperties(&prop, plan->device));
@@ -267,6 +330,7 @@ int32_t si_fft_tables_create(pds_si_plan *plan, const double *taps) {
 void si_fft_tables_destroy(pds_si_plan *plan) {
   (void)hipFree(plan->fft.d_spectra);
   (void)hipFree(plan->fft.d_twiddle);
+  (void)hipFree(plan->fft.d_twiddle2k);
   plan->fft = SiFftTables();
 }
 
@@ -294,6 +358,7 @@ int32_t launch_si_fft(const pds_si_plan *plan, const float *d_signal, const int6
   p.blocks_per_utt = transforms * plan->fft.blocks;
   p.spectra = plan->fft.d_spectra;
   p.twiddle = plan->fft.d_twiddle;
+  p.twiddle2k = plan->fft.d_twiddle2k;
   p.window = plan->d_window_f32;
   p.start = start;
   p.S = d.frame_shift;
@@ -302,9 +367,11 @@ int32_t launch_si_fft(const pds_si_plan *plan, const float *d_signal, const int6
   p.use_power = d.use_power;
   const size_t smem = ((size_t)2 * kWaves * kL * kRowStride) * sizeof(float2) +
                       (size_t)2 * p.blocks * p.S * sizeof(float);
-  PDS_HIP(hipFuncSetAttribute((const void *)si_fft_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-  dim3 grid((unsigned)((transforms + 2 * kWaves - 1) / (2 * kWaves)), (unsigned)B);
-  hipLaunchKernelGGL(si_fft_kernel, grid, dim3(kWaves * 64), smem, (hipStream_t)stream, p);
+  auto kern = plan->fft.big ? si_fft_kernel<true> : si_fft_kernel<false>;
+  const int per_wg = plan->fft.big ? kWaves : 2 * kWaves;  // transforms per workgroup
+  PDS_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+  dim3 grid((unsigned)((transforms + per_wg - 1) / per_wg), (unsigned)B);
+  hipLaunchKernelGGL(kern, grid, dim3(kWaves * 64), smem, (hipStream_t)stream, p);
   PDS_HIP(hipGetLastError());
   const int64_t items = max_frames * d.num_coeffs;
   dim3 grid2((unsigned)((items + 255) / 256), (unsigned)B);

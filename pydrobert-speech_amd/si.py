@@ -151,6 +151,11 @@ class ShortIntegrationFrameComputer(LinearFilterBankFrameComputer):
         return self._dft_size
 
     @property
+    def fft_size(self) -> int:
+        """Transform size of the float32 overlap-save kernel for this bank (0: direct filtering)"""
+        return int(_native.lib().pds_si_plan_fft_size(self._native_plan().handle))
+
+    @property
     def taps(self) -> np.ndarray:
         """``(num_coeffs, max_support)`` FIR taps, the energy impulse first if included"""
         return self._taps

@@ -125,6 +125,14 @@ def test_fft_and_direct_forms_agree_and_cover_the_fixtures(gsi):
         close(fft.cpu().numpy(), direct.cpu().numpy(), **F32)
 
 
+def test_transform_size_follows_the_filter_supports():
+    sizes = {name: build(name).fft_size for name in NAMES}
+    assert sizes["s1_gabor_mel"] == 1024 and sizes["s4_gabor_8k_short"] == 1024
+    assert sizes["s6_fbank_long"] == 2048  # 1037 taps: beyond 1024 - S
+    big = alias_factory_subclass_from_arg(FrameComputer, {"name": "si", "bank": {"name": "fbank", "num_filts": 40}})
+    assert big._max_support > 2048 and big.fft_size == 0  # ~7000 taps: direct form only
+
+
 def test_real_bank_with_long_supports_against_oracle():
     # triangular filters are real (half the multiplies) and long (support ~750 samples)
     comp = alias_factory_subclass_from_arg(

@@ -53,7 +53,7 @@ def draw_stft(rng):
 
 
 def draw_si(rng):
-    rate = int(rng.choice([8000, 16000]))
+    rate = int(rng.choice([8000, 16000, 32000, 48000]))  # the higher rates reach the 2048-point form
     cfg = {"name": "si", "bank": draw_bank(rng, rate), "frame_shift_ms": float(rng.choice([5, 10, 12.5, 20])),
            "use_power": bool(rng.random() < 0.5), "use_log": bool(rng.random() < 0.8),
            "include_energy": bool(rng.random() < 0.4)}
