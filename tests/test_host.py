@@ -255,3 +255,42 @@ def test_product_package_never_imports_the_oracle():
             if f.endswith((".py", ".hip", ".h", ".cpp")):
                 text = open(os.path.join(dirpath, f)).read()
                 assert "import oracle" not in text and "from oracle" not in text, f
+
+
+def test_new_entry_points_validate_arguments_without_a_device():
+    # argument checks come before any HIP call: they can be exercised on a machine without a GPU
+    lib = _native.lib()
+    assert ctypes.sizeof(_native.SiDesc) == 40
+    null = None
+    rc = lib.pds_stack_rows_f32(null, 4, null, null, null, 1, 1, 4, 0, 0, null, 4, null)  # num_vectors 0
+    assert rc < 0 and b"stack_rows" in lib.pds_last_error()
+    rc = lib.pds_stack_rows_f32(null, 4, null, null, null, 1, 1, 4, 2, 0, null, 8, null)  # null pointers
+    assert rc < 0 and b"null pointer" in lib.pds_last_error()
+    assert lib.pds_stack_rows_f32(null, 4, null, null, null, 0, 0, 4, 2, 0, null, 8, null) == 0  # empty batch
+    rc = lib.pds_si_batch_f32(null, null, null, null, null, null, 1, 1, 0, null, null, 1, null)
+    assert rc < 0 and b"null plan" in lib.pds_last_error()
+    assert lib.pds_si_scratch_len(null, 4, 100) == 0 and lib.pds_si_plan_fft_size(null) == 0
+    desc = _native.SiDesc(frame_shift=0, max_support=10, num_coeffs=1, taps_complex=0, use_power=1, use_log=1,
+                          reserved=0, reserved2=0, log_floor=1e-5)
+    handle = ctypes.c_void_p()
+    taps = np.zeros(10)
+    rc = lib.pds_si_plan_create(ctypes.byref(desc), taps.ctypes.data, taps.ctypes.data, ctypes.byref(handle))
+    assert rc < 0 and b"frame_shift" in lib.pds_last_error()
+    rc = lib.pds_deltas_rows_f32(null, 4, null, null, 1, 5, 4, null, null, 2, 4, null, 4, null)
+    assert rc < 0 and b"deltas_rows" in lib.pds_last_error()
+
+
+def test_widened_classes_have_no_cpu_path_either():
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is visible")
+    from pydrobert_speech_amd.pre import Dither, Preemphasize
+
+    si = build({"name": "si", "bank": {"name": "gabor", "scaling_function": "mel", "num_filts": 3}})
+    for call in (lambda: si.compute_full(np.zeros(1000, dtype=np.float32)),
+                 lambda: si.compute_chunk(np.zeros(1000, dtype=np.float32)),
+                 lambda: Preemphasize().apply(np.zeros(10, dtype=np.float32)),
+                 lambda: Dither().apply(np.zeros(10, dtype=np.float32))):
+        with pytest.raises(_native.NativeError, match="no HIP device"):
+            call()
