@@ -65,6 +65,13 @@ WORKLOADS = {
          "use_power": True, "pad_to_nearest_power_of_two": False},
         160000, 1024, None,
     ),
+    # long analysis frames (music / audio tagging): 80 mel, 48 kHz, 50 ms frames -> N = 4096, one frame
+    # per wavefront
+    "fbank80_48k_50_12.5_b256x10s": (
+        {"name": "stft", "bank": {"name": "fbank", "num_filts": 80, "sampling_rate": 48000},
+         "frame_length_ms": 50, "frame_shift_ms": 12.5, "use_power": True},
+        480000, 256, None,
+    ),
     # short-integration features, 40 complex Gabor filters (supports up
     # to 380 taps) + energy; compute bound (direct time-domain filtering), so a smaller batch
     "si_gabor40_b64x10s": (

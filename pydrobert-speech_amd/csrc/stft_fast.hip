@@ -135,8 +135,10 @@ struct WaveGeom {
   static constexpr int PSTR = ((NB + 1 + 15) / 32) * 32 + 16;
   static_assert(GROUPS * PSTR <= EXCH_F2 * 2, "P must fit over the exchange area");
   static_assert(EXCH_F2 * 2 >= 64 * NROWS, "edge-frame gather reuses the exchange area");
-  static_assert(N % 2 == 0 && CPL >= 1 && N2 <= 32 && (RS * 8) % 16 == 0, "geometry");
-  static_assert(inl::is_pow2(N1) ? FULL : 600 % N1 == 0, "in-lane DFT sizes: 2^k, or a divisor of 600");
+  static_assert(N % 2 == 0 && CPL >= 1 && N2 <= 64 && (RS * 8) % 16 == 0, "geometry");
+  // (N = 4096 = 64 x 64 has 32 columns for 64 lanes: the upper half of the wave idles in step 3)
+  static_assert(inl::is_pow2(N1) ? (FULL || N2 == 64) : 600 % N1 == 0,
+                "in-lane DFT sizes: 2^k, or a divisor of 600");
   static_assert(NROWS <= N1 && NROWS > 0, "rows");
 };
 
@@ -501,7 +503,8 @@ __global__ __launch_bounds__(MAXWAVES * 64, MINW) void stft_wave_kernel(const Fa
       energy = dpp_add<0x4E>(energy);   // quad_perm [2,3,0,1]
       energy = dpp_add<0x141>(energy);  // row_half_mirror
       if constexpr (N2 >= 16) energy = dpp_add<0x140>(energy);  // row_mirror
-      if constexpr (N2 == 32) energy += __shfl_xor(energy, 16, 64);
+      if constexpr (N2 >= 32) energy += __shfl_xor(energy, 16, 64);
+      if constexpr (N2 == 64) energy += __shfl_xor(energy, 32, 64);
       float e = energy * p.inv_L;
       if (!use_power) e = __builtin_amdgcn_sqrtf(e);
       if (p.use_log) e = fast_log(p.log_floor > e ? p.log_floor : e);
@@ -660,7 +663,7 @@ static int32_t launch_wave(const pds_stft_plan *plan, const BatchArgs &a) {
 // Instantiated geometries.  N -> (N1, N2); row counts cover the common frame lengths exactly
 // (e.g. 25 ms @ 16 kHz = 400 samples = 25 rows of 16) and round other lengths up.
 //   N = 128 : 16 x 8      N = 256 : 32 x 8      N = 512 : 32 x 16
-//   N = 1024: 64 x 16     N = 2048: 64 x 32
+//   N = 1024: 64 x 16     N = 2048: 64 x 32     N = 4096: 64 x 64 (one frame per wavefront)
 // Transforms without zero padding (N = L, every row in use), N1 x N2:
 //   160: 20 x 8    200: 25 x 8    240: 30 x 8    320: 20 x 16   400: 25 x 16   480: 30 x 16
 //   640: 20 x 32   800: 25 x 32   960: 30 x 32
@@ -688,6 +691,9 @@ int32_t launch_stft_fast_f32(const pds_stft_plan *plan, const BatchArgs &a) {
     case 2048:
       PDS_GEOM_ROWS(64, 32, 35, 2) PDS_GEOM_ROWS(64, 32, 38, 2) PDS_GEOM_ROWS(64, 32, 48, 2)
       PDS_GEOM_ROWS(64, 32, 64, 2)
+      break;
+    case 4096:  // one frame per wavefront, one wavefront per SIMD (512 registers)
+      PDS_GEOM_ROWS(64, 64, 38, 1) PDS_GEOM_ROWS(64, 64, 48, 1) PDS_GEOM_ROWS(64, 64, 64, 1)
       break;
     case 160: PDS_GEOM_ROWS(20, 8, 20, 4) break;
     case 200: PDS_GEOM_ROWS(25, 8, 25, 4) break;
@@ -718,6 +724,7 @@ int32_t fast_tables_create(pds_stft_plan *plan, const double *window, const int3
     case 512: n1 = 32; n2 = 16; break;
     case 1024: n1 = 64; n2 = 16; break;
     case 2048: n1 = 64; n2 = 32; break;
+    case 4096: n1 = 64; n2 = 64; break;
     case 160: n1 = 20; n2 = 8; break;
     case 200: n1 = 25; n2 = 8; break;
     case 240: n1 = 30; n2 = 8; break;

@@ -198,6 +198,13 @@ EXTRA_GEOMETRIES = {
     # N = 2048, magnitude spectrum, complex bank, causal frames
     "n2048_gammatone_44k": {"name": "stft", "bank": {"name": "gammatone", "scaling_function": "bark",
                             "num_filts": 30, "sampling_rate": 44100}, "frame_length_ms": 30, "use_power": False},
+    # N = 4096 (64 x 64: one frame per wavefront): 50 ms at 48 kHz, and 80 ms at 44.1 kHz with energy,
+    # a complex bank and the magnitude spectrum
+    "n4096_fbank_48k": {"name": "stft", "bank": {"name": "fbank", "num_filts": 80, "sampling_rate": 48000},
+                        "frame_length_ms": 50, "frame_shift_ms": 12.5, "use_power": True},
+    "n4096_gabor_44k": {"name": "stft", "bank": {"name": "gabor", "scaling_function": "mel", "num_filts": 48,
+                        "sampling_rate": 44100}, "frame_length_ms": 80, "frame_shift_ms": 20,
+                        "use_power": False, "include_energy": True, "frame_style": "causal"},
     # N = 1024 with every row in use (L = 1024)
     "n1024_full_rows": {"name": "stft", "bank": {"name": "tri", "scaling_function": "mel", "num_filts": 50,
                         "sampling_rate": 32000}, "frame_length_ms": 32, "frame_shift_ms": 8, "use_power": True},

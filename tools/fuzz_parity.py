@@ -39,7 +39,7 @@ def draw_bank(rng, rate):
 
 def draw_stft(rng):
     rate = int(rng.choice([8000, 16000, 22050, 32000, 44100, 48000]))
-    ms = float(rng.choice([10, 12.5, 16, 20, 25, 30, 32, 40]))
+    ms = float(rng.choice([10, 12.5, 16, 20, 25, 30, 32, 40, 50, 64, 80]))  # 50+ ms: N = 4096 at 44.1 / 48 kHz
     cfg = {"name": "stft", "bank": draw_bank(rng, rate), "frame_length_ms": ms,
            "frame_shift_ms": float(rng.choice([5, 8, 10, 12.5, 16])),
            "use_power": bool(rng.random() < 0.7), "use_log": bool(rng.random() < 0.8),
