@@ -65,6 +65,12 @@ WORKLOADS = {
          "use_power": True, "pad_to_nearest_power_of_two": False},
         160000, 1024, None,
     ),
+    # 48 kHz audio with the usual 25 ms / 10 ms framing: L = 1200 -> N = 2048 (64 x 32, two frames per wave)
+    "fbank80_48k_25_10_b256x10s": (
+        {"name": "stft", "bank": {"name": "fbank", "num_filts": 80, "sampling_rate": 48000},
+         "frame_length_ms": 25, "frame_shift_ms": 10, "use_power": True},
+        480000, 256, None,
+    ),
     # long analysis frames (music / audio tagging): 80 mel, 48 kHz, 50 ms frames -> N = 4096, one frame
     # per wavefront
     "fbank80_48k_50_12.5_b256x10s": (

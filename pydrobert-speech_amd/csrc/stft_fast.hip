@@ -126,6 +126,8 @@ struct WaveGeom {
   static constexpr int COLS = NREG + 1;     // + column 0: the real-valued outputs (k1 = 0, and N1/2 if even)
   static constexpr int CPL = (COLS + N2 - 1) / N2;  // step-3 columns per lane
   static constexpr bool FULL = COLS % N2 == 0;      // every lane owns CPL columns (powers of two)
+  // the packed real column (multiples of N1/2) is untangled by lanes 0..N2/2, one bin pair each
+  static constexpr bool DIST = N2 >= 16;
   static constexpr int GROUPS = 64 / N2;    // frames per wave iteration
   static constexpr int NB = N / 2 + 1;      // half-spectrum bins
   static constexpr int RS = N2 + 2;         // exchange row stride (float2): conflict-free
@@ -373,7 +375,7 @@ __global__ __launch_bounds__(MAXWAVES * 64, MINW) void stft_wave_kernel(const Fa
     wave_sync();
 
     float pw[G::CPL][N2 + 1];
-    float sp0 = 0.0f, sp1 = 0.0f;  // N2 == 16: the two special bins of lane r <= N2/2
+    float sp0 = 0.0f, sp1 = 0.0f;  // the two special bins of lane r <= N2/2
 #pragma unroll
     for (int q = 0; q < G::CPL; ++q) {
       const int kk = q * N2 + r;
@@ -401,18 +403,26 @@ __global__ __launch_bounds__(MAXWAVES * 64, MINW) void stft_wave_kernel(const Fa
       } else {
         inl::CFFT<N2, 1>::run(zr, zi, Yr, Yi);
       }
-      if constexpr (N2 == 16) {
-        // regular columns; lane 0 (q = 0) holds Y = FFT(c[2m] + i c[2m+1]) of the even/odd sums
+      // regular columns; lane 0 (q = 0) holds Y = FFT(c[2m] + i c[2m+1]) of the even/odd sums
 #pragma unroll
-        for (int k2 = 0; k2 < N2; ++k2) pw[q][k2] = Yr[k2] * Yr[k2] + Yi[k2] * Yi[k2];
-        pw[q][N2] = 0.0f;
-        if (q == 0) {
-          // The bins m * N1/2 need Y[m] and Y[N2 - m]: a lane group is one DPP row, so
-          // "row_shr:m, keep old where the source lane is outside the row", applied for
-          // m = 1, 2, ... in order, leaves lane m with lane 0's register m.  Lanes 0..N2/2 then
-          // untangle one bin pair each -- 32 moves + 20 flops for every lane instead of a
-          // ~130-instruction block that only lane 0 needs.
-          float ar = Yr[0], ai = Yi[0], br = Yr[0], bi = Yi[0];
+      for (int k2 = 0; k2 < N2; ++k2) pw[q][k2] = Yr[k2] * Yr[k2] + Yi[k2] * Yi[k2];
+      pw[q][N2] = 0.0f;
+      if constexpr (!G::DIST) {
+        // 8 lanes per frame: lane 0 untangles its short packed-sum transform itself (spreading
+        // it would cost registers these geometries do not have)
+        if (q == 0 && r == 0)
+          inl::rdft_finish_power<2 * N2>(Yr, Yi, [&](auto mm, float re, float im) {
+            pw[q][decltype(mm)::value] = re * re + im * im;
+          });
+      } else if (q == 0) {
+        // The bins m * N1/2 need Y[m] and Y[N2 - m] of that lane: lanes 0..N2/2 untangle one bin
+        // pair each -- a few moves + 20 flops for every lane instead of a block of ~10 N2
+        // instructions that only lane 0 needs.
+        float ar, ai, br, bi;
+        if constexpr (N2 == 16) {
+          // a lane group is one DPP row, so "row_shr:m, keep old where the source lane is outside
+          // the row", applied for m = 1, 2, ... in order, leaves lane m with lane 0's register m
+          ar = Yr[0], ai = Yi[0], br = Yr[0], bi = Yi[0];
           inl::static_for<1, N2 / 2 + 1>([&](auto mm) {
             constexpr int m = decltype(mm)::value;
             ar = dpp_row_shr_keep<m>(ar, Yr[m]);
@@ -420,24 +430,25 @@ __global__ __launch_bounds__(MAXWAVES * 64, MINW) void stft_wave_kernel(const Fa
             br = dpp_row_shr_keep<m>(br, Yr[N2 - m]);
             bi = dpp_row_shr_keep<m>(bi, Yi[N2 - m]);
           });
-          const float sr = ar + br, si = ai - bi;
-          const float dr = ar - br, di = ai + bi;
-          const float tr = sw.x * di + sw.y * dr;
-          const float ti = sw.y * di - sw.x * dr;
-          const float xr = sr + tr, xi = si + ti;  // 2 X[m]
-          const float yr = sr - tr, yi = ti - si;  // 2 X[N2 - m]
-          sp0 = 0.25f * (xr * xr + xi * xi);
-          sp1 = 0.25f * (yr * yr + yi * yi);
-        }
-      } else if (q == 0 && r == 0) {
-        // other lane-group sizes: lane 0 untangles its packed-sum transform itself
-        inl::rdft_finish_power<2 * N2>(Yr, Yi, [&](auto mm, float re, float im) {
-          pw[q][decltype(mm)::value] = re * re + im * im;
-        });
-      } else {
+        } else {
+          // other group sizes: lane 0 hands its column over through row 0 of the frame's exchange
+          // block (its only reader, lane 0 itself, is past it)
+          if (r == 0) {
 #pragma unroll
-        for (int k2 = 0; k2 < N2; ++k2) pw[q][k2] = Yr[k2] * Yr[k2] + Yi[k2] * Yi[k2];
-        pw[q][N2] = 0.0f;
+            for (int k2 = 0; k2 < N2; ++k2) exch[k2] = make_float2(Yr[k2], Yi[k2]);
+          }
+          wave_sync();
+          const float2 ya = exch[r], yb = exch[(N2 - r) & (N2 - 1)];
+          ar = ya.x, ai = ya.y, br = yb.x, bi = yb.y;
+        }
+        const float sr = ar + br, si = ai - bi;
+        const float dr = ar - br, di = ai + bi;
+        const float tr = sw.x * di + sw.y * dr;
+        const float ti = sw.y * di - sw.x * dr;
+        const float xr = sr + tr, xi = si + ti;  // 2 X[m]
+        const float yr = sr - tr, yi = ti - si;  // 2 X[N2 - m]
+        sp0 = 0.25f * (xr * xr + xi * xi);
+        sp1 = 0.25f * (yr * yr + yi * yi);
       }
     }
     if (!use_power) {
@@ -464,14 +475,14 @@ __global__ __launch_bounds__(MAXWAVES * 64, MINW) void stft_wave_kernel(const Fa
 #pragma unroll
     for (int q = 0; q < G::CPL; ++q) {
       const int kk = q * N2 + r;
-      if (N2 != 16 && q == 0 && r == 0) {
+      if (!G::DIST && q == 0 && r == 0) {
         // output m of the 2 N2-point transform is bin m N1 / 2 (odd N1: even m only)
 #pragma unroll
         for (int m = 0; m <= N2; m += (N1 % 2 ? 2 : 1)) Pg[m * N1 / 2] = pw[q][m];
       } else {
-        // (N2 == 16: lane 0 of q = 0 writes its meaningless column to multiples of N1, all of
-        // which the special bins written next overwrite).  Lanes beyond the last column (only
-        // when the columns do not fill the lanes) send theirs to the padding slot.
+        // (DIST: lane 0 of q = 0 writes its meaningless column to multiples of N1, all of which
+        // the special bins written next overwrite).  Lanes beyond the last column (only when the
+        // columns do not fill the lanes) send theirs to the padding slot.
         const bool live = G::FULL || kk < COLS;
 #pragma unroll
         for (int k2 = 0; k2 < N2; ++k2) {
@@ -481,7 +492,8 @@ __global__ __launch_bounds__(MAXWAVES * 64, MINW) void stft_wave_kernel(const Fa
         }
       }
     }
-    if constexpr (N2 == 16) {
+    if constexpr (G::DIST) {
+      // output m of the 2 N2-point transform is bin m N1 / 2 (odd N1: even m only)
       const bool has = r <= N2 / 2 && (N1 % 2 == 0 || r % 2 == 0);
       Pg[has ? r * N1 / 2 : PSTR - 1] = sp0;
       Pg[has ? (N2 - r) * N1 / 2 : PSTR - 1] = sp1;
