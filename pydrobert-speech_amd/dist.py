@@ -14,7 +14,7 @@ from typing import List, Optional, Sequence, Tuple
 
 import numpy as np
 
-__all__ = ["gather_rows", "shard_bounds", "compute_full_sharded"]
+__all__ = ["all_reduce_stats", "gather_rows", "shard_bounds", "compute_full_sharded"]
 
 
 def shard_bounds(num_items: int, world_size: int, rank: int) -> Tuple[int, int]:
@@ -70,6 +70,42 @@ def gather_rows(local, group=None, dst: Optional[int] = None):
     if dst is not None and dist.get_rank(group) != dst:
         return None
     return out
+
+
+def all_reduce_stats(standardize, group=None) -> None:
+    """Sum the statistics a ``Standardize`` (``CMVN``) accumulated on every rank, in place
+
+    Global (corpus-level) normalisation with the corpus sharded by utterance: every rank calls
+    ``accumulate`` on its own feature matrices (reference post.py:193-212), then this -- one
+    all-reduce of the float64 ``[2, C + 1]`` table of sums, sums of squares and the count
+    (about 1 KB) -- after which ``apply`` uses the same statistics on every rank.  A rank that
+    accumulated nothing (an empty shard) contributes zeros.
+    """
+    import torch
+    import torch.distributed as dist
+
+    if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return
+    dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else "cpu"
+    stats = standardize._stats
+    width = torch.tensor([0 if stats is None else stats.shape[1]], dtype=torch.int64, device=dev)
+    widest = width.clone()
+    dist.all_reduce(widest, op=dist.ReduceOp.MAX, group=group)
+    widest = int(widest.item())
+    # every rank takes part in both collectives before anyone raises, so a mismatch cannot
+    # leave the others waiting
+    ok = torch.tensor([int(stats is None or stats.shape[1] == widest)], dtype=torch.int64, device=dev)
+    dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)
+    if not int(ok.item()):
+        raise ValueError("ranks accumulated statistics of different widths")
+    if widest == 0:
+        return
+    table = torch.zeros((2, widest), dtype=torch.float64) if stats is None else torch.from_numpy(
+        np.ascontiguousarray(stats, dtype=np.float64)
+    )
+    table = table.to(dev)
+    dist.all_reduce(table, op=dist.ReduceOp.SUM, group=group)
+    standardize._stats = table.cpu().numpy()
 
 
 def compute_full_sharded(computer, signals: Sequence, gather: bool = True, group=None):

@@ -69,6 +69,30 @@ WORKER = textwrap.dedent(
         assert a.shape == b.shape and np.array_equal(a, b)
     lo, own = compute_full_sharded(FakeComputer(), signals, gather=False)
     assert lo == shard_bounds(len(signals), world, rank)[0]
+    # global CMVN statistics: the sum over ranks of what each accumulated; a rank with an empty
+    # shard (no statistics yet) contributes zeros
+    from pydrobert_speech_amd.dist import all_reduce_stats
+    from pydrobert_speech_amd.post import Standardize
+    cmvn = Standardize()
+    if rank == 0:
+        cmvn._stats = np.array([[1.0, 2.0, 3.0, 10.0], [4.0, 5.0, 6.0, 0.0]])
+    all_reduce_stats(cmvn)
+    assert np.array_equal(cmvn._stats, [[1.0, 2.0, 3.0, 10.0], [4.0, 5.0, 6.0, 0.0]]), cmvn._stats
+    cmvn._stats = cmvn._stats * (rank + 1)
+    all_reduce_stats(cmvn)
+    total = sum(r + 1 for r in range(world))
+    assert np.array_equal(cmvn._stats, np.array([[1.0, 2.0, 3.0, 10.0], [4.0, 5.0, 6.0, 0.0]]) * total)
+    if rank == 1:
+        cmvn._stats = np.zeros((2, 7))
+    try:
+        all_reduce_stats(cmvn)
+    except ValueError as err:
+        assert "different widths" in str(err)
+    else:
+        raise AssertionError("width mismatch not reported")
+    empty = Standardize()
+    all_reduce_stats(empty)
+    assert empty._stats is None
     dist.barrier()
     dist.destroy_process_group()
     open(os.path.join(os.environ["PDS_OUT"], f"rank{rank}.ok"), "w").write("ok")
