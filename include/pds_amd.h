@@ -67,6 +67,9 @@ typedef struct pds_stft_plan pds_stft_plan;
  * val    : host, double[nnz]   weight = (2 if bank.is_real) * sum |H_f[k]|^p over the taps
  *                              k that land on that bin (p = 2 if use_power else 1)
  * Replaces: the tables `_window`, `_filt_start_idxs`, `_truncated_filts` (compute.py:352-359).
+ * A plan's tables live on the device that is current when it is created; batch calls made while
+ * another device is current return PDS_ERR_INVALID (create one plan per device -- plans are
+ * immutable and may be shared by the threads and streams of their device).
  */
 int32_t pds_stft_plan_create(const pds_stft_desc *desc, const double *window,
                              const int32_t *row_ptr, const int32_t *col, const double *val,

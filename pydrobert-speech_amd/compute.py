@@ -282,7 +282,7 @@ class ShortTimeFourierTransformFrameComputer(LinearFilterBankFrameComputer):
         self._row_ptr, self._col, self._val = bin_weight_table(
             self._filt_start_idxs, self._truncated_filts, self._dft_size, self._real, self._power
         )
-        self._plan = None
+        self._plans = {}  # device index -> _NativePlan (tables live on one GPU)
         self._reset_stream()
 
     # ---- properties ---------------------------------------------------------------
@@ -338,8 +338,13 @@ class ShortTimeFourierTransformFrameComputer(LinearFilterBankFrameComputer):
 
     # ---- native plumbing ----------------------------------------------------------
 
-    def _native_plan(self) -> _NativePlan:
-        if self._plan is None:
+    def _native_plan(self, device=None) -> _NativePlan:
+        """The plan for `device` (a torch device or index; default: the current device)"""
+        torch = _native.require_device()
+        index = torch.cuda.current_device() if device is None else torch.device(device).index
+        if index is None:
+            index = torch.cuda.current_device()
+        if index not in self._plans:
             desc = _native.StftDesc(
                 frame_length=self._frame_length,
                 frame_shift=self._frame_shift,
@@ -353,8 +358,9 @@ class ShortTimeFourierTransformFrameComputer(LinearFilterBankFrameComputer):
                 reserved=0,
                 log_floor=self._log_floor,
             )
-            self._plan = _NativePlan(desc, self._window, self._row_ptr, self._col, self._val)
-        return self._plan
+            with torch.cuda.device(index):  # the plan's tables are allocated on the current device
+                self._plans[index] = _NativePlan(desc, self._window, self._row_ptr, self._col, self._val)
+        return self._plans[index]
 
     def prepare_layout(self, offsets, lengths, nframes=None, device="cuda") -> "PackedLayout":
         """Describe a packed batch once; reuse it for every launch with that geometry
@@ -403,9 +409,9 @@ class ShortTimeFourierTransformFrameComputer(LinearFilterBankFrameComputer):
         """
         torch = _native.require_device()
         lib = _native.lib()
-        plan = self._native_plan()
         if not signal.is_cuda or signal.dim() != 1 or not signal.is_contiguous():
             raise ValueError("signal must be a contiguous 1-D tensor on the GPU")
+        plan = self._native_plan(signal.device)
         if layout.extent > signal.numel():
             raise ValueError("an utterance lies outside the signal buffer")
         if signal.dtype == torch.float64 and config.FLOAT64_ARITHMETIC == "float32" and not generic:

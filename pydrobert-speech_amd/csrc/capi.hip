@@ -23,6 +23,15 @@ static int32_t invalid(const std::string &msg) {
   return PDS_ERR_INVALID;
 }
 
+int32_t check_plan_device(int plan_device, const char *what) {
+  int current = -1;
+  PDS_HIP(hipGetDevice(&current));
+  if (current != plan_device)
+    return invalid(std::string(what) + ": the plan was created on device " + std::to_string(plan_device) +
+                   ", the current device is " + std::to_string(current) + " (one plan per device)");
+  return PDS_OK;
+}
+
 }  // namespace pds
 
 using pds::invalid;
@@ -138,6 +147,8 @@ static int32_t check_batch(const pds_stft_plan *plan, const void *sig, const int
   int32_t rc = check_batch(plan, d_signal, d_offsets, d_lengths, d_nframes, d_row_off, B,    \
                            max_frames, pad_left, d_out, out_stride);                         \
   if (rc == 1) return PDS_OK;                                                                \
+  if (rc != PDS_OK) return rc;                                                               \
+  rc = pds::check_plan_device(plan->device, "stft_batch");                                   \
   if (rc != PDS_OK) return rc;                                                               \
   pds::BatchArgs a{d_signal, d_offsets,  d_lengths,                                          \
                    d_nframes, d_row_off, B,                                                  \

@@ -107,6 +107,9 @@ int32_t fast_tables_create(pds_stft_plan *plan, const double *window, const int3
 void fast_tables_destroy(pds_stft_plan *plan);
 int32_t launch_stft_fast_f32(const pds_stft_plan *plan, const BatchArgs &a);
 
+// capi.hip: PDS_OK when the calling thread's current device is the one a plan's tables live on
+int32_t check_plan_device(int plan_device, const char *what);
+
 // host helper: upload a host array
 template <typename T>
 int32_t upload(T **dst, const T *src, size_t count) {

@@ -161,6 +161,7 @@ static int32_t launch_si(const pds_si_plan *plan, const T *d_signal, const int64
     return invalid_si("si_batch: null pointer");
   const pds_si_desc &d = plan->d;
   if (out_stride < d.num_coeffs) return invalid_si("si_batch: out_stride < num_coeffs");
+  if (int32_t rc = check_plan_device(plan->device, "si_batch"); rc != PDS_OK) return rc;
   const int S = d.frame_shift;
   int JB = (kSiThreads * kSiR) / S;
   if (JB < 2) JB = 2;  // long shifts: two blocks per tile, several passes of the thread block
@@ -258,7 +259,8 @@ int32_t pds_si_batch_f32(const pds_si_plan *plan, const float *d_signal, const i
                          const int64_t *d_row_off, int32_t B, int64_t max_frames, int64_t start,
                          float *d_scratch, float *d_out, int64_t out_stride, void *stream) {
   if (plan && d_scratch && plan->fft.blocks > 0 && B > 0 && B <= 65535 && max_frames > 0 && d_signal &&
-      d_offsets && d_lengths && d_nframes && d_row_off && d_out && out_stride >= plan->d.num_coeffs)
+      d_offsets && d_lengths && d_nframes && d_row_off && d_out && out_stride >= plan->d.num_coeffs &&
+      pds::check_plan_device(plan->device, "si_batch") == PDS_OK)  // (the direct form reports a mismatch)
     return pds::launch_si_fft(plan, d_signal, d_offsets, d_lengths, d_nframes, d_row_off, B, max_frames,
                               start, d_scratch, d_out, out_stride, stream);
   return pds::launch_si<float>(plan, d_signal, d_offsets, d_lengths, d_nframes, d_row_off, B,

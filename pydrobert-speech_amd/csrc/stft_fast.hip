@@ -28,6 +28,7 @@
 // Measured alternatives are recorded in DESIGN.md (batch kernel with workgroup barriers and a
 // lane = frame filter phase: 0.76 G frames/s; this design: 2.2 G frames/s on one MI355X).
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -654,12 +655,16 @@ static int32_t launch_wave(const pds_stft_plan *plan, const BatchArgs &a) {
   auto kern = pre      ? stft_wave_kernel<N1, N2, NROWS, CU_WAVES, MINW, true, true>
               : in_lds ? stft_wave_kernel<N1, N2, NROWS, CU_WAVES, MINW, true, false>
                        : stft_wave_kernel<N1, N2, NROWS, CU_WAVES, MINW, false, false>;
-  static size_t attr_smem[3] = {0, 0, 0};  // per instantiation
+  // the dynamic-LDS limit is an attribute of the kernel on one device: raised once per
+  // (instantiation, device, variant) and remembered (relaxed atomics: a lost race repeats the call)
+  constexpr int kDevices = 64;
+  static std::atomic<size_t> attr_smem[kDevices][3];
   const int which = pre ? 2 : (in_lds ? 1 : 0);
-  if (smem > attr_smem[which]) {
+  const bool cached = plan->device >= 0 && plan->device < kDevices;
+  if (!cached || smem > attr_smem[plan->device][which].load(std::memory_order_relaxed)) {
     PDS_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)smem));
-    attr_smem[which] = smem;
+    if (cached) attr_smem[plan->device][which].store(smem, std::memory_order_relaxed);
   }
   int64_t grid = (int64_t)ft.num_cus * wgs_per_cu;
   const int64_t need = (chunks * a.B + waves - 1) / waves;

@@ -121,7 +121,7 @@ class ShortIntegrationFrameComputer(LinearFilterBankFrameComputer):
         skip = translation - S if frame_style == "centered" else translation
         # samples consumed before integration starts / virtual zeros in front (compute.py:859-865)
         self._skip0, self._lead = (skip, 0) if skip >= 0 else (0, -skip)
-        self._plan = None
+        self._plans = {}  # device index -> _SiPlan (tables live on one GPU)
         self._reset_stream()
 
     # -- properties (compute.py:746-778) ------------------------------------------------------
@@ -184,22 +184,28 @@ class ShortIntegrationFrameComputer(LinearFilterBankFrameComputer):
 
     # -- device ----------------------------------------------------------------------------------
 
-    def _native_plan(self) -> _SiPlan:
-        if self._plan is None:
+    def _native_plan(self, device=None) -> _SiPlan:
+        """The plan for `device` (a torch device or index; default: the current device)"""
+        torch = _native.require_device()
+        index = torch.cuda.current_device() if device is None else torch.device(device).index
+        if index is None:
+            index = torch.cuda.current_device()
+        if index not in self._plans:
             desc = _native.SiDesc(
                 frame_shift=self._frame_shift, max_support=self._max_support, num_coeffs=self.num_coeffs,
                 taps_complex=int(not self._real), use_power=int(self._power), use_log=int(self._log),
                 reserved=0, reserved2=0, log_floor=self._log_floor,
             )
             taps = self._taps if self._real else self._taps.view(np.float64)
-            self._plan = _SiPlan(desc, taps, self._window.reshape(-1))
-        return self._plan
+            with torch.cuda.device(index):  # the plan's tables are allocated on the current device
+                self._plans[index] = _SiPlan(desc, taps, self._window.reshape(-1))
+        return self._plans[index]
 
     def _launch(self, signal, meta, lo, hi, max_frames, start, out, direct=False):
         """One native call for utterances ``lo:hi`` of the device index rows `meta`"""
         torch = _native.require_device()
         lib = _native.lib()
-        plan = self._native_plan()
+        plan = self._native_plan(signal.device)
         stream = torch.cuda.current_stream(signal.device).cuda_stream
         args = (plan.handle, signal.data_ptr(), meta[0, lo:].data_ptr(), meta[1, lo:].data_ptr(),
                 meta[2, lo:].data_ptr(), meta[3, lo:].data_ptr(), hi - lo, max_frames, start)

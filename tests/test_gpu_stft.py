@@ -321,3 +321,29 @@ def test_streaming_random_chunkings_match_reference_call_by_call(name, computers
         outs = [comp.compute_chunk(p) for p in pieces] + [comp.finalize()]
         assert [len(o) for o in outs] == g[f"{name}/{case}/counts"].tolist(), (name, case)
         assert_features_close(np.concatenate(outs), g[f"{name}/{case}/feats"], what=(name, case), **F32)
+
+
+def test_plans_are_per_device(computers):
+    # a computer keeps one native plan per GPU; the C ABI refuses a plan on another device
+    import torch
+
+    comp = computers["c2_tri_mel40"]
+    plan0 = comp._native_plan(torch.device("cuda", 0))
+    assert comp._native_plan(0) is plan0 and comp._native_plan("cuda:0") is plan0
+    if torch.cuda.device_count() < 2:
+        pytest.skip("one GPU: the cross-device half needs two")
+    x = torch.randn(16000, device="cuda:1")
+    y1, _ = comp.compute_packed(x, [0], [16000])
+    y0, _ = comp.compute_packed(x.to("cuda:0"), [0], [16000])
+    assert y1.device.index == 1 and torch.equal(y1.cpu(), y0.cpu())
+    from pydrobert_speech_amd import _native
+
+    lib = _native.lib()
+    layout = comp.prepare_layout([0], [16000], device="cuda:1")
+    out = torch.empty((100, comp.num_coeffs), device="cuda:1")
+    meta = layout.d_meta
+    with torch.cuda.device(1):
+        rc = lib.pds_stft_batch_f32(plan0.handle, x.data_ptr(), meta[0].data_ptr(), meta[1].data_ptr(),
+                                    meta[2].data_ptr(), meta[3].data_ptr(), 1, 100, -1, 0.0, out.data_ptr(),
+                                    out.stride(0), None)
+    assert rc != 0 and b"created on device 0" in lib.pds_last_error()
