@@ -29,6 +29,7 @@ extern "C" {
 #define PDS_OK 0
 #define PDS_ERR_INVALID -1 /* bad argument / unsupported configuration */
 #define PDS_ERR_HIP -2     /* a HIP runtime call failed                  */
+#define PDS_ERR_NOMEM -3   /* host memory exhausted while building a plan */
 
 /* library version, major * 10000 + minor * 100 + patch */
 int32_t pds_version(void);

@@ -162,6 +162,8 @@ def check(rc: int, what: str) -> None:
         msg = last_error()
         if rc == -1:
             raise ValueError(f"{what}: {msg}")
+        if rc == -3:
+            raise MemoryError(f"{what}: {msg}")
         raise NativeError(f"{what}: {msg} (code {rc})")
 
 

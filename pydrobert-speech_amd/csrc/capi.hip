@@ -68,37 +68,40 @@ int32_t pds_stft_plan_create(const pds_stft_desc *desc, const double *window,
   for (int e = 0; e < d.nnz; ++e)
     if (col[e] < 0 || col[e] >= num_bins) return invalid("plan_create: col out of range");
 
-  pds_stft_plan *p = new pds_stft_plan();
-  p->d = d;
-  p->num_bins = num_bins;
-  if (hipGetDevice(&p->device) != hipSuccess) {
-    delete p;
-    return invalid("plan_create: no HIP device");
-  }
-  std::vector<float> wf(d.frame_length), vf(d.nnz);
-  for (int i = 0; i < d.frame_length; ++i) wf[i] = (float)window[i];
-  for (int i = 0; i < d.nnz; ++i) vf[i] = (float)val[i];
-  std::vector<float2> twf(d.dft_size);
-  std::vector<double2> twd(d.dft_size);
-  for (int j = 0; j < d.dft_size; ++j) {
-    // exact quadrant handling keeps cos/sin of multiples of pi/2 exact
-    const double ang = 2.0 * M_PI * (double)j / (double)d.dft_size;
-    twd[j] = make_double2(std::cos(ang), std::sin(ang));
-    twf[j] = make_float2((float)twd[j].x, (float)twd[j].y);
-  }
-  int32_t rc = PDS_OK;
-  if (rc == PDS_OK) rc = pds::upload(&p->d_window_f32, wf.data(), wf.size());
-  if (rc == PDS_OK) rc = pds::upload(&p->d_window_f64, window, (size_t)d.frame_length);
-  if (rc == PDS_OK) rc = pds::upload(&p->d_row_ptr, row_ptr, (size_t)d.num_filts + 1);
-  if (rc == PDS_OK) rc = pds::upload(&p->d_col, col, (size_t)d.nnz);
-  if (rc == PDS_OK) rc = pds::upload(&p->d_val_f32, vf.data(), vf.size());
-  if (rc == PDS_OK) rc = pds::upload(&p->d_val_f64, val, (size_t)d.nnz);
-  if (rc == PDS_OK) rc = pds::upload(&p->d_tw_f32, twf.data(), twf.size());
-  if (rc == PDS_OK) rc = pds::upload(&p->d_tw_f64, twd.data(), twd.size());
-  if (rc == PDS_OK) rc = pds::fast_tables_create(p, window, row_ptr, col, val);
-  if (rc != PDS_OK) {
-    pds_stft_plan_destroy(p);
+  int device = -1;
+  if (hipGetDevice(&device) != hipSuccess) return invalid("plan_create: no HIP device");
+  pds_stft_plan *p = nullptr;
+  const int32_t status = pds::no_throw("plan_create", [&]() -> int32_t {
+    p = new pds_stft_plan();
+    p->d = d;
+    p->num_bins = num_bins;
+    p->device = device;
+    std::vector<float> wf(d.frame_length), vf(d.nnz);
+    for (int i = 0; i < d.frame_length; ++i) wf[i] = (float)window[i];
+    for (int i = 0; i < d.nnz; ++i) vf[i] = (float)val[i];
+    std::vector<float2> twf(d.dft_size);
+    std::vector<double2> twd(d.dft_size);
+    for (int j = 0; j < d.dft_size; ++j) {
+      // exact quadrant handling keeps cos/sin of multiples of pi/2 exact
+      const double ang = 2.0 * M_PI * (double)j / (double)d.dft_size;
+      twd[j] = make_double2(std::cos(ang), std::sin(ang));
+      twf[j] = make_float2((float)twd[j].x, (float)twd[j].y);
+    }
+    int32_t rc = PDS_OK;
+    if (rc == PDS_OK) rc = pds::upload(&p->d_window_f32, wf.data(), wf.size());
+    if (rc == PDS_OK) rc = pds::upload(&p->d_window_f64, window, (size_t)d.frame_length);
+    if (rc == PDS_OK) rc = pds::upload(&p->d_row_ptr, row_ptr, (size_t)d.num_filts + 1);
+    if (rc == PDS_OK) rc = pds::upload(&p->d_col, col, (size_t)d.nnz);
+    if (rc == PDS_OK) rc = pds::upload(&p->d_val_f32, vf.data(), vf.size());
+    if (rc == PDS_OK) rc = pds::upload(&p->d_val_f64, val, (size_t)d.nnz);
+    if (rc == PDS_OK) rc = pds::upload(&p->d_tw_f32, twf.data(), twf.size());
+    if (rc == PDS_OK) rc = pds::upload(&p->d_tw_f64, twd.data(), twd.size());
+    if (rc == PDS_OK) rc = pds::fast_tables_create(p, window, row_ptr, col, val);
     return rc;
+  });
+  if (status != PDS_OK) {
+    pds_stft_plan_destroy(p);  // frees whatever was built (null-safe)
+    return status;
   }
   *plan_out = p;
   return PDS_OK;

@@ -3,6 +3,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <exception>
+#include <new>
 #include <string>
 
 #include "../../include/pds_amd.h"
@@ -106,6 +108,20 @@ int32_t fast_tables_create(pds_stft_plan *plan, const double *window, const int3
                            const int32_t *col, const double *val);
 void fast_tables_destroy(pds_stft_plan *plan);
 int32_t launch_stft_fast_f32(const pds_stft_plan *plan, const BatchArgs &a);
+
+// Runs `body` (plan construction: host allocations) so that no C++ exception crosses the C ABI.
+template <typename F>
+int32_t no_throw(const char *what, F &&body) {
+  try {
+    return body();
+  } catch (const std::bad_alloc &) {
+    set_error(std::string(what) + ": out of host memory");
+    return PDS_ERR_NOMEM;
+  } catch (const std::exception &err) {
+    set_error(std::string(what) + ": " + err.what());
+    return PDS_ERR_INVALID;
+  }
+}
 
 // capi.hip: PDS_OK when the calling thread's current device is the one a plan's tables live on
 int32_t check_plan_device(int plan_device, const char *what);

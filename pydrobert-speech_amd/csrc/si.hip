@@ -212,24 +212,30 @@ int32_t pds_si_plan_create(const pds_si_desc *desc, const double *taps, const do
   if (d.frame_shift < 1 || d.max_support < 1 || d.num_coeffs < 1 || d.reserved != 0 || d.reserved2 != 0)
     return pds::invalid_si("si_plan_create: need frame_shift, max_support, num_coeffs >= 1");
   if (!(d.log_floor > 0.0)) return pds::invalid_si("si_plan_create: log_floor must be positive");
-  pds_si_plan *plan = new pds_si_plan();
-  plan->d = d;
-  PDS_HIP(hipGetDevice(&plan->device));
-  const int R = pds::kSiR, M = d.max_support, C = d.num_coeffs, w = d.taps_complex ? 2 : 1;
-  plan->mpad = (M + R - 1) / R * R;
-  std::vector<double> t64((size_t)C * plan->mpad * w, 0.0);
-  for (int c = 0; c < C; ++c)
-    for (int k = 0; k < M * w; ++k) t64[(size_t)c * plan->mpad * w + k] = taps[(size_t)c * M * w + k];
-  std::vector<float> t32(t64.begin(), t64.end());
-  std::vector<float> w32(window, window + 2 * (size_t)d.frame_shift);
-  int32_t rc = pds::upload(&plan->d_taps_f64, t64.data(), t64.size());
-  if (rc == PDS_OK) rc = pds::upload(&plan->d_taps_f32, t32.data(), t32.size());
-  if (rc == PDS_OK) rc = pds::upload(&plan->d_window_f64, window, 2 * (size_t)d.frame_shift);
-  if (rc == PDS_OK) rc = pds::upload(&plan->d_window_f32, w32.data(), w32.size());
-  if (rc == PDS_OK) rc = pds::si_fft_tables_create(plan, taps);
-  if (rc != PDS_OK) {
-    pds_si_plan_destroy(plan);
+  int device = -1;
+  PDS_HIP(hipGetDevice(&device));
+  pds_si_plan *plan = nullptr;
+  const int32_t status = pds::no_throw("si_plan_create", [&]() -> int32_t {
+    plan = new pds_si_plan();
+    plan->d = d;
+    plan->device = device;
+    const int R = pds::kSiR, M = d.max_support, C = d.num_coeffs, w = d.taps_complex ? 2 : 1;
+    plan->mpad = (M + R - 1) / R * R;
+    std::vector<double> t64((size_t)C * plan->mpad * w, 0.0);
+    for (int c = 0; c < C; ++c)
+      for (int k = 0; k < M * w; ++k) t64[(size_t)c * plan->mpad * w + k] = taps[(size_t)c * M * w + k];
+    std::vector<float> t32(t64.begin(), t64.end());
+    std::vector<float> w32(window, window + 2 * (size_t)d.frame_shift);
+    int32_t rc = pds::upload(&plan->d_taps_f64, t64.data(), t64.size());
+    if (rc == PDS_OK) rc = pds::upload(&plan->d_taps_f32, t32.data(), t32.size());
+    if (rc == PDS_OK) rc = pds::upload(&plan->d_window_f64, window, 2 * (size_t)d.frame_shift);
+    if (rc == PDS_OK) rc = pds::upload(&plan->d_window_f32, w32.data(), w32.size());
+    if (rc == PDS_OK) rc = pds::si_fft_tables_create(plan, taps);
     return rc;
+  });
+  if (status != PDS_OK) {
+    pds_si_plan_destroy(plan);  // frees whatever was built (null-safe)
+    return status;
   }
   *plan_out = plan;
   return PDS_OK;
