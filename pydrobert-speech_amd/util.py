@@ -1,6 +1,8 @@
 """Helpers shared by the banks, and the signal readers either side of the hot path.
 
-* ``hertz_to_angular`` / ``angular_to_hertz`` (reference util.py:108-115);
+* ``hertz_to_angular`` / ``angular_to_hertz`` (reference util.py:108-115), ``gauss_quant``
+  (util.py:54-104) and ``circshift_fourier`` (util.py:118-185): host-side helpers the reference
+  exports beside them;
 * ``read_signal`` (reference util.py:362-510): same selection rules, arguments and error
   behaviour for the sources that need nothing outside this image -- ``wav`` (scipy, else the
   standard ``wave`` module), ``npy``, ``npz``, ``pt``, ``file`` (``numpy.fromfile``).  Kaldi
@@ -11,12 +13,14 @@
 Torch files are loaded with ``weights_only=True``: a signal or feature file is a tensor, and
 nothing from the file is executed.
 """
+import math
 import re
 from typing import Any, BinaryIO, Optional, Union
 
 import numpy as np
 
-__all__ = ["angular_to_hertz", "hertz_to_angular", "read_signal", "SIGNAL_SOURCES"]
+__all__ = ["angular_to_hertz", "circshift_fourier", "gauss_quant", "hertz_to_angular", "read_signal",
+           "SIGNAL_SOURCES"]
 
 
 def hertz_to_angular(hertz: float, samp_rate: float) -> float:
@@ -27,6 +31,62 @@ def hertz_to_angular(hertz: float, samp_rate: float) -> float:
 def angular_to_hertz(angle: float, samp_rate: float) -> float:
     """radians/sample -> cycles/sec"""
     return angle * samp_rate / (2 * np.pi)
+
+
+def _standard_normal_quantile(p: float) -> float:
+    """z with Phi(z) = p, by Newton steps on ``math.erfc`` from a bracketing start (no scipy)"""
+    if not 0.0 <= p <= 1.0:
+        return float("nan")
+    if p in (0.0, 1.0):
+        return -math.inf if p == 0.0 else math.inf
+    tail = min(p, 1.0 - p)  # solve in the lower tail, mirror afterwards
+    z = -math.sqrt(-2.0 * math.log(tail))  # below the root: Phi(z) < tail for every tail < 1/2
+    for _ in range(60):
+        cdf = 0.5 * math.erfc(-z / math.sqrt(2.0))
+        pdf = math.exp(-0.5 * z * z) / math.sqrt(2.0 * math.pi)
+        step = (cdf - tail) / pdf
+        z -= step
+        if abs(step) <= 1e-15 * max(1.0, abs(z)):
+            break
+    return z if p < 0.5 else -z
+
+
+def gauss_quant(p: float, mu: float = 0, std: float = 1) -> float:
+    """Quantile function (inverse CDF) of a Gaussian with mean `mu` and deviation `std`
+
+    ``scipy.special.ndtri`` when scipy is importable (the reference uses ``scipy.stats.norm.ppf``,
+    the same function; util.py:73-78), else Newton iterations on the error function (the
+    reference falls back to a rational approximation good to ~1e-8 instead; util.py:54-70).
+    """
+    try:
+        from scipy.special import ndtri
+
+        z = float(ndtri(p))
+    except ImportError:
+        z = _standard_normal_quantile(float(p))
+    return z * std + mu
+
+
+def circshift_fourier(filt: np.ndarray, shift: float, start_idx: int = 0, dft_size: Optional[int] = None,
+                      copy: bool = True) -> np.ndarray:
+    """Shift a filter circularly by `shift` samples in time, given its frequency response
+
+    The shift theorem: bin k of the response is multiplied by ``exp(-2 pi i k shift / dft_size)``.
+    `filt` may be a truncated response whose first entry is bin `start_idx` of a `dft_size`-point
+    transform (default ``len(filt) + start_idx``; bins wrap modulo `dft_size`).  Returns a
+    complex128 array; with ``copy=False`` a complex128 `filt` is modified in place and returned
+    (reference util.py:118-185 -- which takes ``shift % dft_size`` before applying the default and
+    so needs `dft_size` given; here the default is resolved first).
+    """
+    if dft_size is None:
+        dft_size = len(filt) + start_idx
+    shift = shift % dft_size
+    bins = np.arange(start_idx, start_idx + len(filt)) % dft_size
+    ramp = np.exp(-2j * np.pi * shift / dft_size * bins)
+    if copy or filt.dtype != np.complex128:
+        return filt * ramp
+    filt *= ramp
+    return filt
 
 
 # ------------------------------------------------------------------ readers ----------

@@ -141,3 +141,53 @@ def test_standardize_save_round_trips(gio, tmp_path):
     np.asarray([-1.0, 2.5, 3.0]).tofile(str(junk))
     with pytest.raises(IOError):
         Standardize(str(junk), force_as="file")
+
+
+# ---- the two numeric helpers util exports beside the readers (reference tests/test_util.py:11-53) ----
+
+
+@pytest.mark.parametrize("shift", [0, 1, -3, 100])
+@pytest.mark.parametrize("dft_size", [1, 2, 51, 256])
+@pytest.mark.parametrize("start_idx", [0, 1, -1])
+@pytest.mark.parametrize("copy", [True, False])
+def test_circshift_fourier_is_a_circular_shift_in_time(shift, dft_size, start_idx, copy):
+    from pydrobert_speech_amd.util import circshift_fourier
+
+    rng = np.random.default_rng(dft_size * 7 + start_idx)
+    start_idx %= dft_size
+    zeros = int(rng.integers(dft_size))
+    X = 10 * rng.random(dft_size - zeros) + 10j * rng.random(dft_size - zeros)
+    given = X.copy()
+    Xs = circshift_fourier(given, shift, start_idx=start_idx, dft_size=dft_size, copy=copy)
+    assert Xs.dtype == np.complex128 and (Xs is given) == (not copy)
+    if copy:
+        assert np.array_equal(given, X)
+    full = np.roll(np.pad(X, (0, zeros)), start_idx)
+    full_s = np.roll(np.pad(Xs, (0, zeros)), start_idx)
+    assert np.allclose(np.roll(np.fft.ifft(full), shift), np.fft.ifft(full_s))
+    # default transform size: the response ends at the last bin
+    assert np.allclose(circshift_fourier(X, shift, start_idx=start_idx),
+                       circshift_fourier(X, shift, start_idx=start_idx, dft_size=len(X) + start_idx))
+    # real input is promoted rather than modified
+    real = np.ones(dft_size)
+    assert circshift_fourier(real, shift, dft_size=dft_size, copy=False).dtype == np.complex128
+    assert np.array_equal(real, np.ones(dft_size))
+
+
+@pytest.mark.parametrize("mu", [0, -1, 100])
+@pytest.mark.parametrize("std", [0.1, 1, 10])
+@pytest.mark.parametrize("with_scipy", [True, False])
+def test_gauss_quant_inverts_the_gaussian_cdf(mu, std, with_scipy, monkeypatch):
+    import math
+    import sys
+
+    from pydrobert_speech_amd import util
+
+    if not with_scipy:
+        monkeypatch.setitem(sys.modules, "scipy.special", None)  # the import inside fails
+    xs = np.linspace(-4.5, 4.5, 181) * std + mu
+    for x in xs:
+        p = 0.5 * math.erfc(-(x - mu) / std / math.sqrt(2))
+        assert np.isclose(util.gauss_quant(p, mu=mu, std=std), x, rtol=0, atol=1e-6 * std + 1e-9 * abs(mu))
+    assert util.gauss_quant(0.5, mu=mu, std=std) == pytest.approx(mu)
+    assert util.gauss_quant(0.0) == -np.inf and util.gauss_quant(1.0) == np.inf
