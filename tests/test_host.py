@@ -202,6 +202,45 @@ def test_frequency_matches_impulse(kind):
         assert np.allclose(np.fft.ifft(X), x, atol=1e-3), (kind, f)
 
 
+def _outside(support_lo, support_hi, count, unit):
+    """mask over `count` grid points (spacing `unit`, periodic with period count * unit): True where
+    no periodic image of the point lies inside [support_lo, support_hi]; None if the support spans
+    more than two periods (nothing to check)"""
+    period = count * unit
+    first, last = int(np.floor(support_lo / period)), int(np.ceil(support_hi / period))
+    if last - first > 2:
+        return None, 0
+    mask = np.ones(count, dtype=bool)
+    for image in range(first, last + 1):
+        at = np.arange(count) * unit + image * period
+        mask &= (at < support_lo) | (at > support_hi)
+    return mask, last - first
+
+
+@pytest.mark.parametrize("kind", sorted(BANKS))
+def test_responses_vanish_outside_the_declared_supports(kind):
+    # reference tests/test_filters.py:148-196: `supports_hz` bounds the frequency response and
+    # `supports` the impulse response, each up to the effective-support threshold per period
+    bank = BANKS[kind](11)
+    eps = ps.config.EFFECTIVE_SUPPORT_THRESHOLD
+    for f in range(bank.num_filts):
+        lo_hz, hi_hz = bank.supports_hz[f]
+        N = int(max(1, 2 * bank.sampling_rate / (hi_hz - lo_hz)))
+        mask, periods = _outside(lo_hz, hi_hz, N, bank.sampling_rate / N)
+        if mask is not None:
+            if bank.is_real:  # a real filter's response is Hermitian: the mirror image counts too
+                mask[1:] &= mask[-1:0:-1]
+            if mask.any():
+                X = bank.get_frequency_response(f, N)
+                assert np.allclose(X[mask], 0, atol=periods * eps), (kind, f, "frequency")
+        lo, hi = bank.supports[f]
+        width = int(max(1, hi - lo))
+        mask, periods = _outside(lo, hi, width, 1)
+        if mask is not None and mask.any() and width <= 3000:
+            x = bank.get_impulse_response(f, width)
+            assert np.allclose(x[mask], 0, atol=periods * eps), (kind, f, "time")
+
+
 @pytest.mark.parametrize("window_size", [10, 100, 1000])
 @pytest.mark.parametrize("peak_ratio", [0.5, 0.75, 0.9])
 @pytest.mark.parametrize("order", [2, 4])
