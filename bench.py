@@ -177,9 +177,10 @@ def main():
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--preroll-ms", type=float, default=60.0,
-                    help="untimed launches before the warm-up, for this many milliseconds: the GPU leaves "
-                         "its idle clock state only after ~40 ms of continuous work (tools/clock_ramp.py: "
-                         "0.38 ms per step at first, 0.32 ms from step ~100 on); 0 disables")
+                    help="untimed launches before the warm-up, for at least this many milliseconds and until "
+                         "the step time has settled: the GPU leaves its idle clock state only after ~40 ms "
+                         "of continuous work (tools/clock_ramp.py: 0.38 ms per step at first, 0.32 ms from "
+                         "step ~100 on), longer after the CPU-baseline leg; 0 disables")
     ap.add_argument("--workload", default=DEFAULT_WORKLOAD, choices=sorted(WORKLOADS))
     ap.add_argument("--batch", type=int, default=None, help="utterances per GPU (default: workload's)")
     ap.add_argument("--ragged", action="store_true",
@@ -297,15 +298,26 @@ def main():
         torch.cuda.synchronize(dev)
 
     # pre-roll (not part of W or K): bring the clocks up so that the timed region measures the
-    # steady state whatever K is
+    # steady state whatever K is.  At least --preroll-ms of work, then on until eight
+    # consecutive blocks of 20 steps have not beaten the fastest block so far by 0.5 % (how long the
+    # clocks take depends on what the box did before: after the CPU-baseline leg the ramp takes
+    # ~150 ms, not ~40), at most 2 s.
     preroll = 0
     if args.preroll_ms > 0:
-        t_end = time.perf_counter() + 1e-3 * args.preroll_ms
-        while time.perf_counter() < t_end:
-            for _ in range(10):
+        t_start = time.perf_counter()
+        best, settled = float("inf"), 0
+        while True:
+            t_block = time.perf_counter()
+            for _ in range(20):
                 step()
             torch.cuda.synchronize(dev)
-            preroll += 10
+            now = time.perf_counter()
+            preroll += 20
+            block = now - t_block
+            settled = 0 if block < 0.995 * best else settled + 1  # (a ramp gains 1-3 % per block)
+            best = min(best, block)
+            if (now - t_start >= 1e-3 * args.preroll_ms and settled >= 8) or now - t_start > 2.0:
+                break
     for _ in range(args.warmup):
         step()
     barrier()
@@ -314,12 +326,18 @@ def main():
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     t0 = time.perf_counter()
     marks[0].record()
+    host_t = [t0]
     for i in range(args.steps):
         step()
         marks[i + 1].record()
+        host_t.append(time.perf_counter())
     barrier()
     elapsed = time.perf_counter() - t0
     kernel_ms = [marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps)]
+    if os.environ.get("PDS_BENCH_DUMP_STEPS"):  # diagnosis: the per-step series
+        with open(os.environ["PDS_BENCH_DUMP_STEPS"], "w") as fh:
+            json.dump({"kernel_ms": kernel_ms,
+                       "host_enqueue_ms": [1e3 * (host_t[i + 1] - host_t[i]) for i in range(args.steps)]}, fh)
     if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

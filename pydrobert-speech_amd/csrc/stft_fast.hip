@@ -41,6 +41,24 @@ namespace pds {
 
 // Timing-only builds (tools/build_variant.sh -DPDS_ABLATE=mask) drop one stage each to see what it
 // costs; results are wrong by construction.  0 in the product build.
+// Wave priority per phase of an item (s_setprio): the four waves of a SIMD run the same sequence
+// of phases, and with equal priorities the issue arbiter lets them drift into the same phase, where
+// they queue for one unit (VALU in the transforms, LDS in the exchange and the filter walk) while
+// the other idles.  Raising the priority as an item ages ("oldest first": loads and the in-lane
+// real DFT 0, exchange and N2-point FFT 1, power spectrum + P stores 2, filter walk 3) keeps the
+// waves staggered: +10 % on the headline workload, +5 ... 10 % on every other geometry with more
+// than one wave per SIMD (tools/ab_libs.sh; flat priorities for the memory phases alone: +7 %,
+// youngest first: +3 %).  One hex digit per phase in PDS_PRIO_PACK, from the lowest digit:
+// 0 record + sample loads, 1 LDS exchange, 2 power spectrum + P stores, 3 filter walk,
+// 4 window + in-lane real DFT, 5 N2-point FFT.  Negative: no hints (tools/build_variant.sh).
+#ifndef PDS_PRIO_PACK
+#define PDS_PRIO_PACK 0x103210
+#endif
+#if PDS_PRIO_PACK == 0xffffff  // (experiment: scheduling barriers at the phase boundaries, no priorities)
+#define PDS_PHASE(i) __builtin_amdgcn_sched_barrier(0)
+#else
+#define PDS_PHASE(i) do { if (PDS_PRIO_PACK >= 0) __builtin_amdgcn_s_setprio(((PDS_PRIO_PACK) >> (4 * (i))) & 3); } while (0)
+#endif
 #ifndef PDS_ABLATE
 #define PDS_ABLATE 0
 #endif
@@ -243,6 +261,7 @@ __global__ __launch_bounds__(MAXWAVES * 64, MINW) void stft_wave_kernel(const Fa
       out_row = load_const(p.row_off + pb);
       continue;
     }
+    PDS_PHASE(0);
     const float *x = p.sig + sig_off;
     // Common case, decided on scalars: all GROUPS frames exist and every row they read lies
     // inside the signal.  Otherwise per-lane bookkeeping: lanes of a frame past the end
@@ -332,6 +351,7 @@ __global__ __launch_bounds__(MAXWAVES * 64, MINW) void stft_wave_kernel(const Fa
         energy = fmaf(v, v, energy);
       }
     }
+    PDS_PHASE(4);
 #pragma unroll
     for (int n1 = 0; n1 < NROWS; ++n1) a[n1] = mul_legacy(a[n1], win[n1]);
 #pragma unroll
@@ -356,6 +376,7 @@ __global__ __launch_bounds__(MAXWAVES * 64, MINW) void stft_wave_kernel(const Fa
     // holds c[j] = sum_q xw[j + 2 N2 q] (j < 2 N2), the input of the multiples of N1/2.  (Odd
     // N1: c[j] = sum_q xw[j + N2 q] for j < N2 and zeros above, whose 2 N2-point transform has
     // the multiples of N1 at its even outputs; the odd ones are not bins and are dropped.)
+    PDS_PHASE(1);
     {
       float *row0 = reinterpret_cast<float *>(exch);
       row0[r] = even_sum;
@@ -402,7 +423,13 @@ __global__ __launch_bounds__(MAXWAVES * 64, MINW) void stft_wave_kernel(const Fa
           Yi[k2] = zi[k2];
         }
       } else {
+        PDS_PHASE(5);
         inl::CFFT<N2, 1>::run(zr, zi, Yr, Yi);
+        if (q + 1 < G::CPL) {
+          PDS_PHASE(1);
+        } else {
+          PDS_PHASE(2);
+        }
       }
       // regular columns; lane 0 (q = 0) holds Y = FFT(c[2m] + i c[2m+1]) of the even/odd sums
 #pragma unroll
@@ -523,6 +550,7 @@ __global__ __launch_bounds__(MAXWAVES * 64, MINW) void stft_wave_kernel(const Fa
       if (p.use_log) e = fast_log(p.log_floor > e ? p.log_floor : e);
       if (valid && r == 0) obase[lane_off - col0] = e;
     }
+    PDS_PHASE(3);
     int metas[USLOTS];  // first bin of the lane's row | (filter + 1) << 16, per slot
 #pragma unroll
     for (int sl = 0; sl < USLOTS; ++sl) metas[sl] = meta_lds[sl * N2 + r];
