@@ -84,7 +84,7 @@ int32_t pds_stft_num_coeffs(const pds_stft_plan *plan);
 int64_t pds_stft_num_frames(const pds_stft_plan *plan, int64_t n);
 /* which kernel family the plan dispatches to for float32 input: the DFT size when a fused
  * LDS/register FFT geometry serves it (128 .. 2048, or an unpadded N = L of 160 .. 960),
- * 0 = generic direct-DFT kernel */
+ * 0 = generic kernels (radix-2 FFT in LDS for powers of two, direct DFT otherwise) */
 int32_t pds_stft_plan_kernel_kind(const pds_stft_plan *plan);
 
 /*
@@ -120,8 +120,8 @@ int32_t pds_stft_batch_f64(const pds_stft_plan *plan, const double *d_signal,
                            const int64_t *d_nframes, const int64_t *d_row_off, int32_t B,
                            int64_t max_frames, int32_t pad_left, double preemph, double *d_out,
                            int64_t out_stride, void *stream);
-/* float32 input through the generic direct-DFT kernel regardless of N (cross-check of
- * the fused kernel; also what non-power-of-two N uses) */
+/* float32 input through the generic kernels regardless of N: radix-2 FFT in LDS for powers of two,
+ * direct DFT otherwise (cross-check of the fused kernel; also what sizes without a fused geometry use) */
 int32_t pds_stft_batch_f32_generic(const pds_stft_plan *plan, const float *d_signal,
                                    const int64_t *d_offsets, const int64_t *d_lengths,
                                    const int64_t *d_nframes, const int64_t *d_row_off,

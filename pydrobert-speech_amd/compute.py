@@ -216,7 +216,8 @@ class ShortTimeFourierTransformFrameComputer(LinearFilterBankFrameComputer):
     Besides the reference's one-signal methods there is a batch interface,
     :func:`compute_full_batch` / :func:`compute_packed`, which is what the GPU is for.
     float32 signals take the fused FFT kernel; float64 signals are computed in float64
-    (the reference's internal precision) by the direct-DFT kernel.
+    (the reference's internal precision) by the generic kernels (an FFT in LDS for power-of-two
+    transform sizes, a direct DFT otherwise).
     """
 
     aliases = {"stft"}
@@ -327,7 +328,7 @@ class ShortTimeFourierTransformFrameComputer(LinearFilterBankFrameComputer):
 
     @property
     def kernel_kind(self) -> int:
-        """1 if float32 input runs the fused FFT kernel, 0 for the direct-DFT kernel"""
+        """The DFT size if float32 input runs the fused FFT kernel, 0 for the generic kernels"""
         return self._native_plan().kernel_kind
 
     def num_frames(self, num_samples: int) -> int:

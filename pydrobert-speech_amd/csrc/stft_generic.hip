@@ -1,4 +1,5 @@
-// Generic STFT filter-bank kernel: any DFT size N, float32 or float64, direct DFT.
+// Generic STFT filter-bank kernels: any DFT size N, float32 or float64 -- a direct DFT for any N
+// (stft_generic_kernel) and, for powers of two, a radix-2 FFT in LDS (stft_fft_kernel, further down).
 //
 // One wavefront per frame.  The frame is reflected/windowed into LDS, every lane
 // evaluates bins k = lane, lane + 64, ... as a dot product over the samples, the
@@ -37,6 +38,14 @@ __device__ __forceinline__ T wave_sum(T v) {
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
   return v;
+}
+
+// one wave owns its LDS area: its LDS operations execute in order, this only keeps the compiler
+// from moving memory operations across the hand-off between lanes
+__device__ __forceinline__ void lds_handoff() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
 template <typename T, int FPB>
@@ -128,6 +137,124 @@ __global__ __launch_bounds__(64 * FPB) void stft_generic_kernel(
   }
 }
 
+// Power-of-two transforms outside the fused kernel's reach (float64 signals; float32 frames longer
+// than 4096 samples): the same frame-per-wavefront layout with the direct DFT replaced by an
+// N/2-point radix-2 FFT in LDS.  The real frame is packed as z[n] = x[2n] + i x[2n+1], stored in
+// bit-reversed order, transformed in place in log2(N/2) passes of N/4 butterflies (twiddles from the
+// plan's N-entry table, so float64 results keep the table's accuracy) and untangled into the
+// N/2 + 1 bins while the power (or magnitude) spectrum is formed.  O(N log N) per frame instead of
+// O(L N): 15 x the direct kernel at N = 512.
+template <typename T, int FPB>
+__global__ __launch_bounds__(64 * FPB) void stft_fft_kernel(
+    const T *__restrict__ sig, const int64_t *__restrict__ offsets,
+    const int64_t *__restrict__ lengths, const int64_t *__restrict__ nframes,
+    const int64_t *__restrict__ row_off, const T *__restrict__ window,
+    const typename Tw<T>::type *__restrict__ tw, const int32_t *__restrict__ row_ptr,
+    const int32_t *__restrict__ col, const T *__restrict__ val, T *__restrict__ out,
+    int64_t out_stride, int L, int S, int N, int log2m, int pad_left, int F, int use_power,
+    int use_log, int include_energy, T log_floor, T preemph) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  using C = typename Tw<T>::type;  // (re, im)
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int b = blockIdx.y;
+  const int64_t nfr = nframes[b];
+  const int64_t t = (int64_t)blockIdx.x * FPB + wave;
+  if (t >= nfr) return;  // whole wave leaves; no block-level barrier is used below
+  const int64_t n = lengths[b];
+  const T *x = sig + offsets[b];
+  const int M = N >> 1;  // complex points
+  // a wave's area: z[M] then pw[M + 1] (rounded up to keep the next wave's z 16-byte aligned)
+  C *z = reinterpret_cast<C *>(smem_raw) + (size_t)wave * (M + (M + 2) / 2);
+  T *pw = reinterpret_cast<T *>(z + M);
+  T *zs = reinterpret_cast<T *>(z);
+
+  // frame -> LDS, windowed, packed and bit-reversed; energy on the un-windowed samples
+  const int64_t start = t * S - pad_left;
+  T e = 0;
+  for (int j = lane; j < N; j += 64) {
+    T v = 0;
+    if (j < L) {
+      const int64_t i = reflect_index(start + j, n);
+      T s = x[i];
+      if (preemph != (T)0 && i > 0) s = preemph_sample(s, x[i - 1], preemph);
+      e += s * s;
+      v = s * window[j];
+    }
+    const unsigned pos = log2m ? __brev((unsigned)(j >> 1)) >> (32 - log2m) : 0u;
+    zs[2 * pos + (j & 1)] = v;
+  }
+  lds_handoff();
+
+  // decimation in time: pass s joins blocks of half = 2^(s-1) points; W_(2 half)^k = tw[k N / (2 half)]
+  for (int s = 1; s <= log2m; ++s) {
+    const int half = 1 << (s - 1);
+    const int tstep = N >> s;
+    for (int q = lane; q < (M >> 1); q += 64) {
+      const int k = q & (half - 1);
+      const int i = ((q - k) << 1) + k, j = i + half;
+      const C w = tw[k * tstep];  // (cos, sin): the forward twiddle is cos - i sin
+      const C a = z[i], c = z[j];
+      const T tr = c.x * w.x + c.y * w.y, ti = c.y * w.x - c.x * w.y;
+      C lo, hi;
+      lo.x = a.x + tr;
+      lo.y = a.y + ti;
+      hi.x = a.x - tr;
+      hi.y = a.y - ti;
+      z[i] = lo;
+      z[j] = hi;
+    }
+    lds_handoff();
+  }
+
+  // untangle: with E = (Z[k] + conj Z[M-k]) / 2 and O = (Z[k] - conj Z[M-k]) / 2i,
+  // X[k] = E + W_N^k O and X[M-k] = conj(E - W_N^k O)
+  for (int k = lane; k <= (M >> 1); k += 64) {
+    const C zk = z[k], zm = z[(M - k) & (M - 1)];
+    const T er = (T)0.5 * (zk.x + zm.x), ei = (T)0.5 * (zk.y - zm.y);
+    const T orr = (T)0.5 * (zk.y + zm.y), oi = (T)0.5 * (zm.x - zk.x);
+    const C w = tw[k];
+    const T pr = orr * w.x + oi * w.y, pi = oi * w.x - orr * w.y;  // W_N^k O
+    const T ar = er + pr, ai = ei + pi, br = er - pr, bi = ei - pi;
+    const T pa = ar * ar + ai * ai, pb = br * br + bi * bi;
+    pw[k] = use_power ? pa : sqrt(pa);
+    pw[M - k] = use_power ? pb : sqrt(pb);
+  }
+  lds_handoff();
+
+  T *orow = out + (row_off[b] + t) * out_stride;
+  if (include_energy) {
+    e = wave_sum(e) / (T)L;
+    if (!use_power) e = sqrt(e);
+    if (use_log) e = log(log_floor > e ? log_floor : e);  // Python max(): NaN stays NaN
+    if (lane == 0) orow[0] = e;
+    orow += 1;
+  }
+  for (int f = lane; f < F; f += 64) {
+    T acc = 0;
+    for (int q = row_ptr[f]; q < row_ptr[f + 1]; ++q) acc += val[q] * pw[col[q]];
+    if (use_log) acc = log(log_floor > acc ? log_floor : acc);
+    orow[f] = acc;
+  }
+}
+
+template <typename T, int FPB>
+static int32_t launch_fft(const pds_stft_plan *p, const BatchArgs &a, const T *window,
+                          const typename Tw<T>::type *tw, const T *val, size_t smem, int log2m) {
+  dim3 grid((unsigned)((a.max_frames + FPB - 1) / FPB), (unsigned)a.B);
+  auto kern = stft_fft_kernel<T, FPB>;
+  if (smem > 64 * 1024)
+    PDS_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)smem));
+  hipLaunchKernelGGL(kern, grid, dim3(64 * FPB), smem, a.stream, (const T *)a.d_signal,
+                     a.d_offsets, a.d_lengths, a.d_nframes, a.d_row_off, window, tw,
+                     p->d_row_ptr, p->d_col, val, (T *)a.d_out, a.out_stride, p->d.frame_length,
+                     p->d.frame_shift, p->d.dft_size, log2m, a.pad_left, p->d.num_filts,
+                     p->d.use_power, p->d.use_log, p->d.include_energy, (T)p->d.log_floor,
+                     (T)a.preemph);
+  PDS_HIP(hipGetLastError());
+  return PDS_OK;
+}
+
 template <typename T, int FPB>
 static int32_t launch_one(const pds_stft_plan *p, const BatchArgs &a, const T *window,
                           const typename Tw<T>::type *tw, const T *val, size_t smem) {
@@ -149,8 +276,16 @@ static int32_t launch_one(const pds_stft_plan *p, const BatchArgs &a, const T *w
 template <typename T>
 static int32_t launch_generic(const pds_stft_plan *p, const BatchArgs &a, const T *window,
                               const typename Tw<T>::type *tw, const T *val) {
-  const size_t per_frame = (size_t)((p->d.frame_length + 15) / 16 * 16 + ((p->num_bins + 3) & ~3)) * sizeof(T);
   const size_t budget = 150 * 1024;
+  const int N = p->d.dft_size;
+  if (N >= 4 && (N & (N - 1)) == 0) {  // power of two: FFT in LDS
+    int log2m = 0;
+    while ((2 << log2m) < N) ++log2m;  // N / 2 = 2^log2m
+    const size_t per_wave = (size_t)(N / 2 + (N / 2 + 2) / 2) * 2 * sizeof(T);
+    if (4 * per_wave <= budget) return launch_fft<T, 4>(p, a, window, tw, val, 4 * per_wave, log2m);
+    if (per_wave <= budget) return launch_fft<T, 1>(p, a, window, tw, val, per_wave, log2m);
+  }
+  const size_t per_frame = (size_t)((p->d.frame_length + 15) / 16 * 16 + ((p->num_bins + 3) & ~3)) * sizeof(T);
   if (4 * per_frame <= budget) return launch_one<T, 4>(p, a, window, tw, val, 4 * per_frame);
   if (per_frame <= budget) return launch_one<T, 1>(p, a, window, tw, val, per_frame);
   set_error("stft_batch: frame_length + dft_size/2 too large for LDS");

@@ -11,7 +11,15 @@ layout = comp.prepare_layout(np.arange(B) * n, np.full(B, n))
 out = comp.launch(x, layout)
 torch.cuda.synchronize()
 t0 = time.perf_counter()
-for _ in range(3): comp.launch(x, layout, out=out)
+for _ in range(20): comp.launch(x, layout, out=out)
 torch.cuda.synchronize()
-dt = (time.perf_counter() - t0) / 3
-print("float64 direct-DFT kernel: %.2f ms per %d frames -> %.1f M frames/s" % (dt * 1e3, layout.total_rows, layout.total_rows / dt / 1e6))
+dt = (time.perf_counter() - t0) / 20
+print("float64 kernel (LDS FFT for this power-of-two size): %.2f ms per %d frames -> %.1f M frames/s" % (dt * 1e3, layout.total_rows, layout.total_rows / dt / 1e6))
+xf = x.to(torch.float32)
+outf = comp.launch(xf, layout, generic=True)
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(20): comp.launch(xf, layout, out=outf, generic=True)
+torch.cuda.synchronize()
+dt = (time.perf_counter() - t0) / 20
+print("float32 generic kernel (same): %.2f ms -> %.1f M frames/s" % (dt * 1e3, layout.total_rows / dt / 1e6))
