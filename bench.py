@@ -411,7 +411,7 @@ def main():
                 "dft_size": comp.dft_size, "parallelism": f"utterance-sharded x{world}",
                 "kernel": ("si-direct-fir" if (args.generic or not comp.fft_size) else
                            f"si-overlap-save-fft{comp.fft_size}") if is_si else
-                          "generic-direct-dft" if (args.generic or not comp.kernel_kind) else "fused-fft",
+                          "generic (lds-fft for 2^k sizes, else direct-dft)" if (args.generic or not comp.kernel_kind) else "fused-fft",
             },
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

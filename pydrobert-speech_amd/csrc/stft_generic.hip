@@ -40,6 +40,24 @@ __device__ __forceinline__ T wave_sum(T v) {
   return v;
 }
 
+// sum of val[q] * pw[col[q]] over one CSR row, four taps in flight (a lane walks its filter alone,
+// so the loads of consecutive taps are what hides their latency)
+template <typename T>
+__device__ __forceinline__ T filter_sum(int q, int end, const int32_t *__restrict__ col,
+                                        const T *__restrict__ val, const T *pw) {
+  T a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+  for (; q + 4 <= end; q += 4) {
+    const int c0 = col[q], c1 = col[q + 1], c2 = col[q + 2], c3 = col[q + 3];
+    const T v0 = val[q], v1 = val[q + 1], v2 = val[q + 2], v3 = val[q + 3];
+    a0 += v0 * pw[c0];
+    a1 += v1 * pw[c1];
+    a2 += v2 * pw[c2];
+    a3 += v3 * pw[c3];
+  }
+  for (; q < end; ++q) a0 += val[q] * pw[col[q]];
+  return (a0 + a1) + (a2 + a3);
+}
+
 // one wave owns its LDS area: its LDS operations execute in order, this only keeps the compiler
 // from moving memory operations across the hand-off between lanes
 __device__ __forceinline__ void lds_handoff() {
@@ -130,8 +148,7 @@ __global__ __launch_bounds__(64 * FPB) void stft_generic_kernel(
     orow += 1;
   }
   for (int f = lane; f < F; f += 64) {
-    T acc = 0;
-    for (int q = row_ptr[f]; q < row_ptr[f + 1]; ++q) acc += val[q] * pw[col[q]];
+    T acc = filter_sum(row_ptr[f], row_ptr[f + 1], col, val, pw);
     if (use_log) acc = log(log_floor > acc ? log_floor : acc);
     orow[f] = acc;
   }
@@ -157,14 +174,19 @@ __global__ __launch_bounds__(64 * FPB) void stft_fft_kernel(
   using C = typename Tw<T>::type;  // (re, im)
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int b = blockIdx.y;
+  const int M = N >> 1;  // complex points
+  // the first half of the twiddle table (all the passes and the untangling need) -> LDS, once per
+  // workgroup: a global-memory round trip per butterfly otherwise
+  C *twl = reinterpret_cast<C *>(smem_raw);
+  for (int i = threadIdx.x; i < M; i += 64 * FPB) twl[i] = tw[i];
+  __syncthreads();
   const int64_t nfr = nframes[b];
   const int64_t t = (int64_t)blockIdx.x * FPB + wave;
   if (t >= nfr) return;  // whole wave leaves; no block-level barrier is used below
   const int64_t n = lengths[b];
   const T *x = sig + offsets[b];
-  const int M = N >> 1;  // complex points
   // a wave's area: z[M] then pw[M + 1] (rounded up to keep the next wave's z 16-byte aligned)
-  C *z = reinterpret_cast<C *>(smem_raw) + (size_t)wave * (M + (M + 2) / 2);
+  C *z = twl + M + (size_t)wave * (M + (M + 2) / 2);
   T *pw = reinterpret_cast<T *>(z + M);
   T *zs = reinterpret_cast<T *>(z);
 
@@ -192,7 +214,7 @@ __global__ __launch_bounds__(64 * FPB) void stft_fft_kernel(
     for (int q = lane; q < (M >> 1); q += 64) {
       const int k = q & (half - 1);
       const int i = ((q - k) << 1) + k, j = i + half;
-      const C w = tw[k * tstep];  // (cos, sin): the forward twiddle is cos - i sin
+      const C w = twl[k * tstep];  // (cos, sin): the forward twiddle is cos - i sin
       const C a = z[i], c = z[j];
       const T tr = c.x * w.x + c.y * w.y, ti = c.y * w.x - c.x * w.y;
       C lo, hi;
@@ -212,7 +234,7 @@ __global__ __launch_bounds__(64 * FPB) void stft_fft_kernel(
     const C zk = z[k], zm = z[(M - k) & (M - 1)];
     const T er = (T)0.5 * (zk.x + zm.x), ei = (T)0.5 * (zk.y - zm.y);
     const T orr = (T)0.5 * (zk.y + zm.y), oi = (T)0.5 * (zm.x - zk.x);
-    const C w = tw[k];
+    const C w = twl[k];
     const T pr = orr * w.x + oi * w.y, pi = oi * w.x - orr * w.y;  // W_N^k O
     const T ar = er + pr, ai = ei + pi, br = er - pr, bi = ei - pi;
     const T pa = ar * ar + ai * ai, pb = br * br + bi * bi;
@@ -230,8 +252,7 @@ __global__ __launch_bounds__(64 * FPB) void stft_fft_kernel(
     orow += 1;
   }
   for (int f = lane; f < F; f += 64) {
-    T acc = 0;
-    for (int q = row_ptr[f]; q < row_ptr[f + 1]; ++q) acc += val[q] * pw[col[q]];
+    T acc = filter_sum(row_ptr[f], row_ptr[f + 1], col, val, pw);
     if (use_log) acc = log(log_floor > acc ? log_floor : acc);
     orow[f] = acc;
   }
@@ -282,8 +303,10 @@ static int32_t launch_generic(const pds_stft_plan *p, const BatchArgs &a, const 
     int log2m = 0;
     while ((2 << log2m) < N) ++log2m;  // N / 2 = 2^log2m
     const size_t per_wave = (size_t)(N / 2 + (N / 2 + 2) / 2) * 2 * sizeof(T);
-    if (4 * per_wave <= budget) return launch_fft<T, 4>(p, a, window, tw, val, 4 * per_wave, log2m);
-    if (per_wave <= budget) return launch_fft<T, 1>(p, a, window, tw, val, per_wave, log2m);
+    const size_t table = (size_t)(N / 2) * 2 * sizeof(T);
+    if (table + 4 * per_wave <= budget)
+      return launch_fft<T, 4>(p, a, window, tw, val, table + 4 * per_wave, log2m);
+    if (table + per_wave <= budget) return launch_fft<T, 1>(p, a, window, tw, val, table + per_wave, log2m);
   }
   const size_t per_frame = (size_t)((p->d.frame_length + 15) / 16 * 16 + ((p->num_bins + 3) & ~3)) * sizeof(T);
   if (4 * per_frame <= budget) return launch_one<T, 4>(p, a, window, tw, val, 4 * per_frame);
