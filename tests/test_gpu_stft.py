@@ -347,3 +347,19 @@ def test_plans_are_per_device(computers):
                                     meta[2].data_ptr(), meta[3].data_ptr(), 1, 100, -1, 0.0, out.data_ptr(),
                                     out.stride(0), None)
     assert rc != 0 and b"created on device 0" in lib.pds_last_error()
+
+
+@pytest.mark.parametrize("dtype", ["f4", "f8"])
+def test_frames_beyond_the_fused_sizes_take_the_lds_fft(dtype):
+    # 100 ms frames at 48 kHz: L = 4800 -> N = 8192, no fused geometry; the generic path runs its
+    # radix-2 FFT in LDS (one frame per workgroup at this size) in the signal's precision
+    comp = build({"name": "stft", "bank": {"name": "fbank", "num_filts": 64, "sampling_rate": 48000},
+                  "frame_length_ms": 100, "frame_shift_ms": 25, "use_power": True, "include_energy": True})
+    assert comp.dft_size == 8192 and comp.kernel_kind == 0
+    p = _params_from_computer(comp)
+    rng = np.random.default_rng(5)
+    sigs = [(3000 * rng.standard_normal(n)).astype(dtype) for n in (0, 2399, 4800, 30011)]
+    tol = F32 if dtype == "f4" else dict(rtol=1e-9, atol=1e-9)
+    for x, y in zip(sigs, comp.compute_full_batch(sigs)):
+        assert y.dtype == x.dtype
+        assert_features_close(y, orc.compute_full(x, p), what=(dtype, len(x)), **tol)
