@@ -18,7 +18,7 @@ LOG_FLOOR_VALUE: float = 1e-5
 
 #: How float64 signals are computed by the STFT computer.  ``"float64"`` (default): float64
 #: arithmetic throughout, the reference's own internal precision, on the generic kernels
-#: (results within 1e-9 of the reference; ~340 M frames/s at power-of-two transform sizes).  ``"float32"``: the samples are
+#: (results within 1e-9 of the reference; ~370 M frames/s at power-of-two transform sizes).  ``"float32"``: the samples are
 #: rounded to float32 on the device, take the fused float32 kernel (results within the
 #: float32 tolerance 1e-5 + 1e-4 |ref|; ~3 G frames/s) and the features are widened back,
 #: so the returned dtype still follows the input as in the reference (compute.py:601).

@@ -157,8 +157,8 @@ __global__ __launch_bounds__(64 * FPB) void stft_generic_kernel(
 // Power-of-two transforms outside the fused kernel's reach (float64 signals; float32 frames longer
 // than 4096 samples): the same frame-per-wavefront layout with the direct DFT replaced by an
 // N/2-point radix-2 FFT in LDS.  The real frame is packed as z[n] = x[2n] + i x[2n+1], stored in
-// bit-reversed order, transformed in place in log2(N/2) passes of N/4 butterflies (twiddles from the
-// plan's N-entry table, so float64 results keep the table's accuracy) and untangled into the
+// bit-reversed order, transformed in place in radix-4 passes (pairs of radix-2 passes; twiddles from
+// the plan's N-entry table, staged in LDS, so float64 results keep the table's accuracy) and untangled into the
 // N/2 + 1 bins while the power (or magnitude) spectrum is formed.  O(N log N) per frame instead of
 // O(L N): 15 x the direct kernel at N = 512.
 template <typename T, int FPB>
@@ -207,21 +207,54 @@ __global__ __launch_bounds__(64 * FPB) void stft_fft_kernel(
   }
   lds_handoff();
 
-  // decimation in time: pass s joins blocks of half = 2^(s-1) points; W_(2 half)^k = tw[k N / (2 half)]
-  for (int s = 1; s <= log2m; ++s) {
+  // decimation in time: pass s joins blocks of half = 2^(s-1) points with W_(2 half)^k = tw[k N / (2 half)].
+  // Passes are taken two at a time (a radix-4 butterfly on i, i + half, i + 2 half, i + 3 half: the
+  // same arithmetic as the two radix-2 passes, half the trips through LDS and half the hand-offs);
+  // an odd pass count ends with one radix-2 pass.
+  auto cmul = [](const C &v, const C &w) {  // v * (w.x - i w.y)
+    C r;
+    r.x = v.x * w.x + v.y * w.y;
+    r.y = v.y * w.x - v.x * w.y;
+    return r;
+  };
+  int s = 1;
+  for (; s + 1 <= log2m; s += 2) {
     const int half = 1 << (s - 1);
-    const int tstep = N >> s;
+    for (int q = lane; q < (M >> 2); q += 64) {
+      const int k = q & (half - 1);
+      const int i = ((q - k) << 2) + k;
+      const C w1 = twl[k * (N >> s)], w2 = twl[k * (N >> (s + 1))];
+      const C a0 = z[i], a1 = cmul(z[i + half], w1), a2 = z[i + 2 * half], a3 = cmul(z[i + 3 * half], w1);
+      C b0, b1, b2, b3;
+      b0.x = a0.x + a1.x, b0.y = a0.y + a1.y;
+      b1.x = a0.x - a1.x, b1.y = a0.y - a1.y;
+      b2.x = a2.x + a3.x, b2.y = a2.y + a3.y;
+      b3.x = a2.x - a3.x, b3.y = a2.y - a3.y;
+      const C c2 = cmul(b2, w2), t3 = cmul(b3, w2);
+      C c3;  // W_(4 half)^(k + half) = -i W_(4 half)^k
+      c3.x = t3.y;
+      c3.y = -t3.x;
+      C o;
+      o.x = b0.x + c2.x, o.y = b0.y + c2.y;
+      z[i] = o;
+      o.x = b1.x + c3.x, o.y = b1.y + c3.y;
+      z[i + half] = o;
+      o.x = b0.x - c2.x, o.y = b0.y - c2.y;
+      z[i + 2 * half] = o;
+      o.x = b1.x - c3.x, o.y = b1.y - c3.y;
+      z[i + 3 * half] = o;
+    }
+    lds_handoff();
+  }
+  if (s == log2m) {
+    const int half = 1 << (s - 1);
     for (int q = lane; q < (M >> 1); q += 64) {
       const int k = q & (half - 1);
       const int i = ((q - k) << 1) + k, j = i + half;
-      const C w = twl[k * tstep];  // (cos, sin): the forward twiddle is cos - i sin
-      const C a = z[i], c = z[j];
-      const T tr = c.x * w.x + c.y * w.y, ti = c.y * w.x - c.x * w.y;
+      const C a = z[i], tq = cmul(z[j], twl[k * (N >> s)]);
       C lo, hi;
-      lo.x = a.x + tr;
-      lo.y = a.y + ti;
-      hi.x = a.x - tr;
-      hi.y = a.y - ti;
+      lo.x = a.x + tq.x, lo.y = a.y + tq.y;
+      hi.x = a.x - tq.x, hi.y = a.y - tq.y;
       z[i] = lo;
       z[j] = hi;
     }
