@@ -571,8 +571,14 @@ __global__ __launch_bounds__(MAXWAVES * 64, MINW) void stft_wave_kernel(const Fa
       // 8 bins per step, two steps per pass of the loop (8 LDS reads in flight per 16
       // multiply-adds); the trip count is a shift of the row length, which is a multiple of 8
       auto step = [&]() {
-        const float4 w0 = wrow[0], w1 = wrow[1];
-        const float4 p0 = prow[0], p1 = prow[1];
+        // weights and powers of one half, then the other: the first multiply-adds wait for two
+        // reads instead of five (LDS returns in order; +3 % on the dense gammatone bank)
+        const float4 w0 = wrow[0];
+        const float4 p0 = prow[0];
+        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+        const float4 w1 = wrow[1];
+        const float4 p1 = prow[1];
+        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
         acc0 = fmaf(w0.x, p0.x, acc0);
         acc1 = fmaf(w0.y, p0.y, acc1);
         acc2 = fmaf(w0.z, p0.z, acc2);
