@@ -42,25 +42,27 @@ def _stream(torch, tensor):
     return torch.cuda.current_stream(tensor.device).cuda_stream
 
 
-_ROWS_META = {}  # one entry: the device copy of the last ragged-row description used
+_ROWS_META = {}  # device copies of the ragged-row descriptions used most recently (insertion-ordered)
+_ROWS_META_ENTRIES = 64
 
 
 def _rows_meta(row_offsets, device):
     """Device ``int64[2][B]`` (first row, row count) of a packed ragged batch + host row counts
 
-    Repeated calls with the same `row_offsets` array (a pipeline processing batch after batch
-    of one geometry) reuse the device copy instead of a host-to-device transfer per launch.
+    Repeated calls with the same `row_offsets` (a pipeline processing batch after batch of a few
+    geometries) reuse the device copy instead of a host-to-device transfer per launch.
     """
     torch = _native.require_device()
     rows = np.ascontiguousarray(row_offsets, dtype=np.int64)
     key = (rows.tobytes(), str(device))
-    hit = _ROWS_META.get("entry")
-    if hit is None or hit[0] != key:
+    hit = _ROWS_META.pop(key, None)
+    if hit is None:
         nrows = np.diff(rows)
-        meta = torch.from_numpy(np.stack([rows[:-1], nrows])).to(device)
-        hit = (key, meta, nrows)
-        _ROWS_META["entry"] = hit
-    return hit[1], hit[2]
+        hit = (torch.from_numpy(np.stack([rows[:-1], nrows])).to(device), nrows)
+        while len(_ROWS_META) >= _ROWS_META_ENTRIES:
+            _ROWS_META.pop(next(iter(_ROWS_META)))  # the least recently used
+    _ROWS_META[key] = hit  # (re-)inserted as the most recent
+    return hit
 
 
 # ------------------------------------------------------------------ Standardize ------
