@@ -34,6 +34,10 @@ struct FastTables {
   int32_t *d_ell_len = nullptr;   // [ell_slots]
   int32_t *d_ell_woff = nullptr;  // [ell_slots]
   int ell_wfloats = 0, ell_slots = 0;
+  // segmented filter walk (16-lane geometries, dense banks): 0 rounds = not built for this plan
+  float *d_seg_w = nullptr;        // [seg_rounds * 64][seg_len + 4]
+  int32_t *d_seg_meta = nullptr;   // [seg_rounds * 64] first bins, then [num_filts] first slot | segments << 16
+  int seg_rounds = 0, seg_len = 0, seg_wfloats = 0, seg_meta_ints = 0;
 };
 
 }  // namespace pds

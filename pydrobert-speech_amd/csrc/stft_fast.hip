@@ -79,7 +79,11 @@ struct FastParams {
   const int32_t *ell_meta;  // [slots][N2] first bin of the row | (filter + 1) << 16
   const int32_t *ell_len;   // [slots] row length in bins (multiple of 8)
   const int32_t *ell_woff;  // [slots] start of the slot's rows inside ell_w (floats)
-  int ell_wfloats, ell_slots, ell_meta_pad;  // meta_pad: ints, multiple of 4
+  int ell_wfloats, ell_slots, ell_meta_pad, ell_meta_ints;  // meta_pad: ints in LDS, multiple of 4; meta_ints: valid ones
+  // segmented filter walk (dense banks, 16-lane frames; see the kernel): when seg_rounds > 0,
+  // ell_w / ell_meta hold its tables instead -- weights [slot][seg_len + 4], then in ell_meta the
+  // slots' first bins [seg_rounds * 64] followed by (first slot | segments << 16) per filter
+  int seg_rounds, seg_len, num_filts;
   int L, S, pad_left, include_energy, use_power, use_log;
   float log_floor, inv_L, preemph;
   int chunks_per_utt, num_utts;
@@ -172,7 +176,9 @@ struct WaveGeom {
 // slots from memory one by one
 constexpr int USLOTS = 4;
 
-template <int N1, int N2, int NROWS, int MAXWAVES, int MINW, bool ELL_LDS, bool PRE>
+// SEG: the filter phase is the segmented walk for dense banks (its own instantiation: inside the
+// ELL kernel its registers cost the headline instantiation three spills)
+template <int N1, int N2, int NROWS, int MAXWAVES, int MINW, bool ELL_LDS, bool PRE, bool SEG = false>
 __global__ __launch_bounds__(MAXWAVES * 64, MINW) void stft_wave_kernel(const FastParams p) {
   using G = WaveGeom<N1, N2, NROWS>;
   constexpr int N = G::N, COLS = G::COLS, NREG = G::NREG, RS = G::RS, NB = G::NB, PSTR = G::PSTR;
@@ -193,7 +199,7 @@ __global__ __launch_bounds__(MAXWAVES * 64, MINW) void stft_wave_kernel(const Fa
   if (threadIdx.x < N2) sw_lds[threadIdx.x] = p.tw_special[threadIdx.x];
   // (slots beyond the table read as "no filter": the unrolled slot loop fetches USLOTS entries)
   for (int i = threadIdx.x; i < p.ell_meta_pad; i += nthreads)
-    meta_lds[i] = i < p.ell_slots * N2 ? p.ell_meta[i] : 0;
+    meta_lds[i] = i < p.ell_meta_ints ? p.ell_meta[i] : 0;
   if constexpr (ELL_LDS)
     for (int i = threadIdx.x; i < p.ell_wfloats; i += nthreads) ellw_lds[i] = p.ell_w[i];
   // the wave areas start out zeroed so that never-written P padding is finite
@@ -555,6 +561,7 @@ __global__ __launch_bounds__(MAXWAVES * 64, MINW) void stft_wave_kernel(const Fa
 #pragma unroll
     for (int sl = 0; sl < USLOTS; ++sl) metas[sl] = meta_lds[sl * N2 + r];
     wave_sync();
+    [[maybe_unused]] const int frames_here = nfr - tb;  // frames of this chunk that exist (SEG)
     // this item's record is dead from here on: fetch the next one under the filter phase
     b = nb;
     chunk = nchunk;
@@ -609,6 +616,76 @@ __global__ __launch_bounds__(MAXWAVES * 64, MINW) void stft_wave_kernel(const Fa
           *reinterpret_cast<float *>(reinterpret_cast<char *>(obase) + byte_off) = acc;
       }
     };
+    if constexpr (SEG) {
+      static_assert(!SEG || (G::GROUPS == 4 && ELL_LDS), "segmented walk: four frames per wave, tables in LDS");
+      {
+        // Segmented walk for dense banks.  The rows of all filters are cut into segments of
+        // seg_len bins and dealt to the 64 lanes, seg_rounds segments each; a lane reads a
+        // segment's weights ONCE and applies them to all four frames of the wave (one 16-byte
+        // weight read per four 16-byte power reads instead of one per one, and no lane waits for
+        // a longer row than its own: every segment has the same length).  Partial sums go to the
+        // part of the wave's area that P leaves free; then lane f adds up filter f's segments for
+        // the four frames and stores four coefficients (64 consecutive floats per store).
+        float4 *part = reinterpret_cast<float4 *>(wbase + G::GROUPS * PSTR);
+        const int steps = p.seg_len >> 2;
+        for (int q = 0; q < p.seg_rounds; ++q) {
+          const int slot = q * 64 + lane;
+          const int first = meta_lds[slot];
+          const float4 *wrow = reinterpret_cast<const float4 *>(ellw_lds + slot * (p.seg_len + 4));
+          const float4 *p0 = reinterpret_cast<const float4 *>(wbase + first);
+          const float4 *p1 = reinterpret_cast<const float4 *>(wbase + PSTR + first);
+          const float4 *p2 = reinterpret_cast<const float4 *>(wbase + 2 * PSTR + first);
+          const float4 *p3 = reinterpret_cast<const float4 *>(wbase + 3 * PSTR + first);
+          float4 acc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+#pragma unroll 2
+          for (int i = 0; i < steps; ++i) {
+            const float4 w = wrow[i];
+            const float4 x0 = p0[i], x1 = p1[i], x2 = p2[i], x3 = p3[i];
+            acc.x = fmaf(w.x, x0.x, acc.x);
+            acc.y = fmaf(w.x, x1.x, acc.y);
+            acc.z = fmaf(w.x, x2.x, acc.z);
+            acc.w = fmaf(w.x, x3.x, acc.w);
+            acc.x = fmaf(w.y, x0.y, acc.x);
+            acc.y = fmaf(w.y, x1.y, acc.y);
+            acc.z = fmaf(w.y, x2.y, acc.z);
+            acc.w = fmaf(w.y, x3.y, acc.w);
+            acc.x = fmaf(w.z, x0.z, acc.x);
+            acc.y = fmaf(w.z, x1.z, acc.y);
+            acc.z = fmaf(w.z, x2.z, acc.z);
+            acc.w = fmaf(w.z, x3.z, acc.w);
+            acc.x = fmaf(w.w, x0.w, acc.x);
+            acc.y = fmaf(w.w, x1.w, acc.y);
+            acc.z = fmaf(w.w, x2.w, acc.z);
+            acc.w = fmaf(w.w, x3.w, acc.w);
+          }
+          part[slot] = acc;
+        }
+        wave_sync();
+        const int *fmeta = meta_lds + p.seg_rounds * 64;
+        for (int f = lane; f < p.num_filts; f += 64) {
+          const int fm = fmeta[f];
+          const float4 *src = part + (fm & 0xffff);
+          float4 sum = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+          for (int k = fm >> 16; k > 0; --k) {
+            const float4 v = *src++;
+            sum.x += v.x;
+            sum.y += v.y;
+            sum.z += v.z;
+            sum.w += v.w;
+          }
+          const float vals[4] = {sum.x, sum.y, sum.z, sum.w};
+#pragma unroll
+          for (int gg = 0; gg < 4; ++gg) {
+            float v = vals[gg];
+            // max(val, floor) as Python evaluates it: a NaN stays a NaN (compute.py:459)
+            if (p.use_log) v = fast_log(p.log_floor > v ? p.log_floor : v);
+            if (gg < frames_here) obase[(int64_t)gg * p.out_stride + col0 + f] = v;
+          }
+        }
+        wave_sync();
+        continue;
+      }
+    }
 #pragma unroll
     for (int sl = 0; sl < USLOTS; ++sl)
       if (sl < p.ell_slots) run_slot(metas[sl], slot_len[sl], slot_woff[sl]);
@@ -664,36 +741,61 @@ static int32_t launch_wave(const pds_stft_plan *plan, const BatchArgs &a) {
   // with the table still in LDS (measured on the 38 KB gammatone table at N = 1024: 6 waves with
   // LDS weights beat 8 waves reading them through L1/L2 by 33 %).  Tables too large even for that
   // stay in global memory.
-  p.ell_meta_pad = (std::max(ft.ell_slots, USLOTS) * N2 + 3) / 4 * 4;
   const size_t lds_cu = 160 * 1024;
   const size_t per_wave = (size_t)G::EXCH_F2 * 8;
-  const size_t fixed = (size_t)N2 * 8 + (size_t)p.ell_meta_pad * 4;
-  const size_t table_bytes = (size_t)ft.ell_wfloats * 4;
   const int shapes[4][2] = {{CU_WAVES / 2, 2}, {CU_WAVES, 1}, {CU_WAVES * 3 / 4, 1}, {CU_WAVES * 5 / 8, 1}};
   int waves = CU_WAVES / 2, wgs_per_cu = 2;
   bool in_lds = false;
-  for (const auto &shape : shapes)
-    if (shape[0] * per_wave + fixed + table_bytes <= lds_cu / shape[1]) {
-      waves = shape[0];
-      wgs_per_cu = shape[1];
-      in_lds = true;
-      break;
-    }
+  // the segmented filter walk (dense banks) when its tables were built and fit in LDS; else the
+  // ELL walk
+  p.seg_rounds = 0;
+  p.seg_len = 0;
+  p.num_filts = plan->d.num_filts;
   const bool pre = a.preemph != 0.0;
+  // (no segmented variant of the fused pre-emphasis kernel: that combination takes the ELL walk)
+  for (int seg = (G::GROUPS == 4 && ft.seg_rounds > 0 && !pre) ? 1 : 0; seg >= 0 && !in_lds; --seg) {
+    const int meta_ints = seg ? ft.seg_meta_ints : ft.ell_slots * N2;
+    const int meta_pad = (std::max(meta_ints, USLOTS * N2) + 3) / 4 * 4;
+    const size_t fixed = (size_t)N2 * 8 + (size_t)meta_pad * 4;
+    const size_t table_bytes = (size_t)(seg ? ft.seg_wfloats : ft.ell_wfloats) * 4;
+    // (segment sums live behind P in the wave's area)
+    if (seg && (size_t)G::GROUPS * G::PSTR * 4 + (size_t)ft.seg_rounds * 64 * 16 > per_wave) continue;
+    for (const auto &shape : shapes)
+      if (shape[0] * per_wave + fixed + table_bytes <= lds_cu / shape[1]) {
+        waves = shape[0];
+        wgs_per_cu = shape[1];
+        in_lds = true;
+        break;
+      }
+    p.ell_meta_pad = meta_pad;
+    p.ell_meta_ints = meta_ints;
+    if (in_lds && seg) {
+      p.ell_w = ft.d_seg_w;
+      p.ell_meta = ft.d_seg_meta;
+      p.ell_wfloats = ft.seg_wfloats;
+      p.seg_rounds = ft.seg_rounds;
+      p.seg_len = ft.seg_len;
+    }
+  }
+  const size_t fixed = (size_t)N2 * 8 + (size_t)p.ell_meta_pad * 4;
+  const size_t table_bytes = (size_t)p.ell_wfloats * 4;
   // the fused pre-emphasis variant exists for LDS-resident tables only; the rare other case
   // (dense complex bank at N >= 1024 plus pre-emphasis) takes the direct-DFT kernel
   if (pre && !in_lds) return launch_stft_generic_f32(plan, a);
   p.preemph = (float)a.preemph;
   p.waves = waves;
   const size_t smem = waves * per_wave + fixed + (in_lds ? table_bytes : 0);
+  constexpr bool HAS_SEG = G::GROUPS == 4;
+  const bool seg = HAS_SEG && p.seg_rounds > 0;
   auto kern = pre      ? stft_wave_kernel<N1, N2, NROWS, CU_WAVES, MINW, true, true>
+              : seg    ? stft_wave_kernel<N1, N2, NROWS, CU_WAVES, MINW, true, false, HAS_SEG>
               : in_lds ? stft_wave_kernel<N1, N2, NROWS, CU_WAVES, MINW, true, false>
                        : stft_wave_kernel<N1, N2, NROWS, CU_WAVES, MINW, false, false>;
   // the dynamic-LDS limit is an attribute of the kernel on one device: raised once per
   // (instantiation, device, variant) and remembered (relaxed atomics: a lost race repeats the call)
   constexpr int kDevices = 64;
-  static std::atomic<size_t> attr_smem[kDevices][3];
-  const int which = pre ? 2 : (in_lds ? 1 : 0);
+  static std::atomic<size_t> attr_smem[kDevices][4];
+  const int which = pre ? 2 : seg ? 3 : (in_lds ? 1 : 0);
   const bool cached = plan->device >= 0 && plan->device < kDevices;
   if (!cached || smem > attr_smem[plan->device][which].load(std::memory_order_relaxed)) {
     PDS_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -886,6 +988,63 @@ int32_t fast_tables_create(pds_stft_plan *plan, const double *window, const int3
   ft.ell_wfloats = (int)ell_w.size();
   ft.ell_slots = slots;
   int32_t rc = PDS_OK;
+  // Segmented walk (16-lane geometries: four frames per wave; see the kernel).  Every filter's
+  // dense row, starting at a multiple of 4 bins, is cut into segments of seg_len bins; a filter's
+  // segments take consecutive slots, slot = round * 64 + lane.  It is used when it needs a fifth
+  // fewer 16-byte LDS reads per item than the ELL walk (two per 4 bins of the longest row of
+  // every slot there; five per 4 bins of a segment and FOUR frames here, plus the sums).
+  if (n2 == 16 && d.num_filts > 0 && d.num_filts <= 65535) {
+    long ell_reads = 0;
+    for (int sl = 0; sl < slots; ++sl) ell_reads += 2L * (ell_len[sl] / 4);  // per item (the 64 lanes cover 4 frames)
+    const int free_slots = ((n1 / 2) * (n2 + 2) * 4 * 2 - 4 * pstr) / 4;  // float4 slots behind P
+    int best_len = 0, best_rounds = 0;
+    long best_reads = 0;
+    for (int len : {16, 32, 64}) {
+      long nseg = 0;
+      for (int f = 0; f < d.num_filts; ++f) nseg += (span(f) + len - 1) / len;
+      const int rounds = (int)((nseg + 63) / 64);
+      if (rounds == 0 || rounds * 64 > free_slots || rounds * 64 > 65535) continue;
+      const long reads = (long)rounds * (len / 4) * 5 + rounds + (nseg + 63) / 64 + 4;
+      if (!best_len || reads < best_reads) best_len = len, best_rounds = rounds, best_reads = reads;
+    }
+    const char *force = std::getenv("PDS_STFT_SEGMENTED");  // "1": whenever feasible, "0": never
+    // (measured: Gammatone-64 at N = 1024, 180 reads against 375: +3.5 %; Gabor-64 at N = 512, 48 against
+    // 64: +5 %; the 40-filter mel bank, 26 against 32: -0.5 %; 80 mel filters, more reads: -2 %)
+    // with four and more ELL slots their per-slot epilogues (log, scattered stores) weigh in as well
+    const bool want = force ? force[0] == '1'
+                            : 5 * best_reads <= 4 * ell_reads || (slots >= 4 && best_reads < ell_reads);
+    if (best_len && want) {
+      const int len = best_len, nslots = best_rounds * 64, wstride = len + 4;
+      std::vector<float> seg_w((size_t)nslots * wstride, 0.0f);
+      std::vector<int32_t> seg_meta((size_t)nslots + d.num_filts, 0);
+      int slot = 0;
+      bool ok = true;
+      for (int f = 0; f < d.num_filts && ok; ++f) {
+        const int count = (span(f) + len - 1) / len;
+        seg_meta[(size_t)nslots + f] = slot | (count << 16);
+        const int base = count ? col[row_ptr[f]] & ~3 : 0;
+        for (int k = 0; k < count; ++k, ++slot) {
+          int first = base + k * len;
+          if (first + len > pstr) first = (pstr - len) & ~3;  // keep every read inside the P row
+          if (first < 0) ok = false;
+          seg_meta[slot] = first;
+          for (int q = row_ptr[f]; q < row_ptr[f + 1]; ++q) {
+            if (col[q] < base + k * len || col[q] >= base + (k + 1) * len) continue;  // this segment's bins
+            const int t = col[q] - first;
+            if (t < 0 || t >= len) ok = false; else seg_w[(size_t)slot * wstride + t] = (float)val[q];
+          }
+        }
+      }
+      if (ok) {
+        ft.seg_rounds = best_rounds;
+        ft.seg_len = len;
+        ft.seg_wfloats = (int)seg_w.size();
+        ft.seg_meta_ints = (int)seg_meta.size();
+        if (rc == PDS_OK) rc = upload(&ft.d_seg_w, seg_w.data(), seg_w.size());
+        if (rc == PDS_OK) rc = upload(&ft.d_seg_meta, seg_meta.data(), seg_meta.size());
+      }
+    }
+  }
   if (rc == PDS_OK) rc = upload(&ft.d_ell_w, ell_w.data(), ell_w.size());
   if (rc == PDS_OK) rc = upload(&ft.d_ell_meta, ell_meta.data(), ell_meta.size());
   if (rc == PDS_OK) rc = upload(&ft.d_ell_len, ell_len.data(), ell_len.size());
@@ -915,6 +1074,8 @@ void fast_tables_destroy(pds_stft_plan *plan) {
   (void)hipFree(ft.d_window);
   (void)hipFree(ft.d_twiddle);
   (void)hipFree(ft.d_tw_special);
+  (void)hipFree(ft.d_seg_w);
+  (void)hipFree(ft.d_seg_meta);
   (void)hipFree(ft.d_ell_w);
   (void)hipFree(ft.d_ell_meta);
   (void)hipFree(ft.d_ell_len);

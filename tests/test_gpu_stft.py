@@ -363,3 +363,34 @@ def test_frames_beyond_the_fused_sizes_take_the_lds_fft(dtype):
     for x, y in zip(sigs, comp.compute_full_batch(sigs)):
         assert y.dtype == x.dtype
         assert_features_close(y, orc.compute_full(x, p), what=(dtype, len(x)), **tol)
+
+
+@pytest.mark.parametrize("bank", ["gammatone64_48k", "gabor64", "mel40"])
+def test_segmented_and_ell_filter_walks_agree(bank, monkeypatch):
+    # the fused kernel has two filter phases (ELL rows per frame; equal-length segments shared by a
+    # wave's four frames, chosen for dense banks): both forced in turn, against the oracle and
+    # against each other, on ragged batches with partial last chunks
+    cfg = {
+        "gammatone64_48k": {"name": "stft", "bank": {"name": "gammatone", "scaling_function": "mel", "num_filts": 64,
+                                                     "sampling_rate": 48000}, "frame_length_ms": 20, "use_power": True},
+        "gabor64": {"name": "stft", "bank": {"name": "gabor", "scaling_function": "mel", "num_filts": 64},
+                    "frame_length_ms": 25, "use_power": True, "include_energy": True},
+        "mel40": {"name": "stft", "bank": {"name": "tri", "scaling_function": "mel", "num_filts": 40},
+                  "frame_length_ms": 25, "use_power": False, "use_log": False},
+    }[bank]
+    rng = np.random.default_rng(11)
+    outs = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("PDS_STFT_SEGMENTED", mode)  # read when the plan is created
+        comp = build(cfg)
+        S = comp.frame_shift
+        sigs = [(3000 * rng.standard_normal(n)).astype("f4") for n in (41 * S + 7, 3 * S, 0, 18 * S + 1, 2 * S - 1)]
+        if mode == "0":
+            keep = sigs
+        outs[mode] = comp.compute_full_batch(keep)
+        p = _params_from_computer(comp)
+        for x, y in zip(keep, outs[mode]):
+            assert_features_close(y, orc.compute_full(x, p), what=(bank, mode, len(x)), **F32)
+    for a, b in zip(outs["0"], outs["1"]):
+        assert a.shape == b.shape
+        np.testing.assert_allclose(a, b, rtol=2e-5, atol=2e-5 * (np.abs(a).max() if a.size else 1))
