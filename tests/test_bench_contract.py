@@ -1,0 +1,63 @@
+"""bench.py's output contract: one JSON line with the driver's fields, `roofline` and `cpu_baseline`."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+DRIVER_FIELDS = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+                 "scaling", "vs_baseline", "dtype", "data", "config", "roofline"}
+ROOFLINE_FIELDS = {"bound", "achieved", "peak", "unit", "frac", "traffic"}
+CPU_FIELDS = {"value", "unit", "cores", "kind", "sample"}
+
+
+def test_cpu_baseline_leg_reports_the_oracle_on_host_cores():
+    # the CPU leg runs before the GPU is touched and needs no device: the oracle in worker processes
+    import bench
+    import pydrobert_speech_amd as ps
+    from pydrobert_speech_amd.alias import alias_factory_subclass_from_arg
+
+    cfg, n, _, _ = bench.WORKLOADS[bench.DEFAULT_WORKLOAD]
+    comp = alias_factory_subclass_from_arg(ps.compute.FrameComputer, cfg)
+    os.environ["OMP_NUM_THREADS"] = "1"
+    res = bench.cpu_baseline(comp, 16000, budget_s=0.002)  # two one-second utterances per worker
+    assert CPU_FIELDS <= set(res)
+    assert res["kind"] == "port" and res["unit"] == "frames/s" and res["value"] > 0 and 1 <= res["cores"] <= 32
+    json.dumps(res)
+
+
+def test_workloads_name_the_baseline_configurations():
+    import bench
+
+    with open(os.path.join(ROOT, "BASELINE.json")) as fh:
+        baseline = json.load(fh)
+    assert bench.DEFAULT_WORKLOAD in bench.WORKLOADS
+    cfg, n, batch, post = bench.WORKLOADS[bench.DEFAULT_WORKLOAD]
+    # configs[1]: 1024 utterances of 10 s at 16 kHz, 40 mel filters, 25 / 10 ms frames
+    assert (n, batch, post) == (160000, 1024, None)
+    assert cfg["bank"]["num_filts"] == 40 and cfg["frame_length_ms"] == 25 and cfg["frame_shift_ms"] == 10
+    assert "40-mel" in baseline["metric"] and "frames/s" in baseline["metric"]
+
+
+@pytest.mark.gpu
+def test_bench_prints_one_json_line_with_the_contract_fields():
+    res = subprocess.run(
+        [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--batch", "16",
+         "--no-cpu-baseline", "--preroll-ms", "5"],
+        capture_output=True, text=True, timeout=600,
+    )
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [l for l in res.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, res.stdout[-2000:]
+    line = json.loads(lines[0])
+    assert DRIVER_FIELDS <= set(line), sorted(DRIVER_FIELDS - set(line))
+    assert ROOFLINE_FIELDS <= set(line["roofline"])
+    assert line["n_gpus"] == 1 and line["steps"] == 3 and line["warmup"] == 1 and line["unit"] == "frames/s"
+    assert line["scaling"] == "weak" and line["higher_is_better"] is True and line["vs_baseline"] is None
+    assert line["dtype"] == "f32" and line["data"] == "synthetic" and "workload" in line["config"]
+    assert line["roofline"]["bound"] == "hbm" and line["roofline"]["peak"] == 8000.0
+    assert 0 < line["roofline"]["frac"] < 1 and line["value"] > 0 and line["outputs_finite"] is True
