@@ -61,3 +61,28 @@ def test_bench_prints_one_json_line_with_the_contract_fields():
     assert line["dtype"] == "f32" and line["data"] == "synthetic" and "workload" in line["config"]
     assert line["roofline"]["bound"] == "hbm" and line["roofline"]["peak"] == 8000.0
     assert 0 < line["roofline"]["frac"] < 1 and line["value"] > 0 and line["outputs_finite"] is True
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_rehearsal_on_one_gpu():
+    # the N > 1 path (launcher environment, barrier, max-over-ranks timing, rank 0 prints) with two
+    # ranks sharing GPU 0 over gloo: RCCL needs one GPU per rank, which the driver's scaling run has
+    import socket
+
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    res = subprocess.run(
+        [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+         "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo",
+         "--steps", "3", "--warmup", "1", "--batch", "16", "--preroll-ms", "5"],
+        capture_output=True, text=True, timeout=900, env=env,
+    )
+    assert res.returncode == 0, res.stderr[-3000:]
+    lines = [l for l in res.stdout.splitlines() if l.strip().startswith("{")]
+    assert len(lines) == 1, res.stdout[-2000:]
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["value"] > 0
+    # whole-job value: both ranks' frames over the slowest rank's time
+    assert line["config"]["frames_per_gpu_per_step"] * 2 * line["steps"] / (line["ms_per_step"] * 1e-3 * line["steps"]) == pytest.approx(line["value"], rel=1e-6)
