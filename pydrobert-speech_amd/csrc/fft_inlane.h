@@ -4,7 +4,8 @@
 // factors are template parameters, so arrays are scalarised into VGPRs and every twiddle
 // is an instruction literal.  Radix-2 decimation in time with the trivial twiddles
 // (1, -i, (1-i)/sqrt2, (-1-i)/sqrt2) specialised, which gives split-radix-like operation
-// counts (N = 16 complex: 144 adds + 24 multiplies).
+// counts (N = 16 complex: 144 adds + 24 multiplies); butterflies with a general twiddle are
+// written in multiply-add form (six instructions instead of eight).
 //
 // Compiles for host and device so the host unit test (tests/test_fft_inlane.py) can
 // exercise the same templates.
@@ -16,6 +17,11 @@
 #include "twiddle_consts.h"
 
 #define PDS_HD __host__ __device__ __forceinline__
+
+// general-twiddle butterflies in multiply-add form (see CFFT::run, rdft_scaled)
+#ifndef PDS_FMA_BUTTERFLY
+#define PDS_FMA_BUTTERFLY 1
+#endif
 
 namespace pds {
 namespace inl {
@@ -80,6 +86,20 @@ struct CFFT {
     CFFT<H, 2 * IS>::run(xr + IS, xi + IS, qr, qi);
     static_for<0, H>([&](auto kk) {
       constexpr int k = decltype(kk)::value;
+      if constexpr (k != 0 && 4 * k != N && 8 * k != N && 8 * k != 3 * N) {
+#if PDS_FMA_BUTTERFLY
+        // general twiddle: e + W q as two chained multiply-adds per component, e - W q as
+        // 2 e - (e + W q): six instructions instead of eight
+        constexpr float c = Tw<N, k>::re, s = Tw<N, k>::im;
+        const float sr = fmaf(qr[k], c, fmaf(-s, qi[k], er[k]));
+        const float si = fmaf(qr[k], s, fmaf(c, qi[k], ei[k]));
+        yr[k] = sr;
+        yi[k] = si;
+        yr[k + H] = fmaf(2.0f, er[k], -sr);
+        yi[k + H] = fmaf(2.0f, ei[k], -si);
+        return;
+#endif
+      }
       float tr, ti;
       mul_tw<N, k>(qr[k], qi[k], tr, ti);
       yr[k] = er[k] + tr;
@@ -150,12 +170,23 @@ PDS_HD void rdft_scaled(const float *a, float &even_sum, float &odd_sum, float *
     const float sr = zr[k] + zr[H - k], si = zi[k] - zi[H - k];
     const float dr = zr[k] - zr[H - k], di = zi[k] + zi[H - k];
     constexpr float wr = Tw<M, k>::re, wi = Tw<M, k>::im;
+#if PDS_FMA_BUTTERFLY
+    // s + W (di - i dr) as chained multiply-adds, the mirrored output from it: ten instructions
+    // per pair instead of twelve
+    const float ar = fmaf(wr, di, fmaf(wi, dr, sr));
+    const float ai = fmaf(wi, di, fmaf(-wr, dr, si));
+    Ar[k] = ar;
+    Ai[k] = ai;
+    Ar[H - k] = fmaf(2.0f, sr, -ar);
+    Ai[H - k] = fmaf(-2.0f, si, ai);
+#else
     const float tr = wr * di + wi * dr;  // W * (di - i dr)
     const float ti = wi * di - wr * dr;
     Ar[k] = sr + tr;
     Ai[k] = si + ti;
     Ar[H - k] = sr - tr;
     Ai[H - k] = ti - si;
+#endif
   });
 }
 
