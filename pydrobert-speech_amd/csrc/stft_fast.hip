@@ -275,7 +275,7 @@ __global__ __launch_bounds__(MAXWAVES * 64, MINW) void stft_wave_kernel(const Fa
     // gathered with reflected indices (1: one bounce suffices, 2: general reflection).
     const int start0 = tb * S - p.pad_left;
     bool valid = true;
-    int start = start0 + g * S;
+    int start = start0 + __mul24(g, S);  // (24-bit multiplies issue at full rate, 32-bit ones at a quarter)
     int wmode = 0;
     if (!(tb + G::GROUPS <= nfr && start0 >= (PRE ? 1 : 0) &&
           start0 + (G::GROUPS - 1) * S + NROWS * N2 <= n)) {
@@ -572,7 +572,7 @@ __global__ __launch_bounds__(MAXWAVES * 64, MINW) void stft_wave_kernel(const Fa
 
     auto run_slot = [&](const int meta, const int len, const int slot_woff_) {
       const float4 *prow = reinterpret_cast<const float4 *>(Pg + (meta & 0xffff));
-      const int woff = slot_woff_ + r * (len + 4);  // + 4: conflict-free row skew
+      const int woff = slot_woff_ + __mul24(r, len + 4);  // + 4: conflict-free row skew
       float acc0 = 0.0f, acc1 = 0.0f, acc2 = 0.0f, acc3 = 0.0f;
       const float4 *wrow = reinterpret_cast<const float4 *>((ELL_LDS ? ellw_lds : p.ell_w) + woff);
       // 8 bins per step, two steps per pass of the loop (8 LDS reads in flight per 16
@@ -631,7 +631,7 @@ __global__ __launch_bounds__(MAXWAVES * 64, MINW) void stft_wave_kernel(const Fa
         for (int q = 0; q < p.seg_rounds; ++q) {
           const int slot = q * 64 + lane;
           const int first = meta_lds[slot];
-          const float4 *wrow = reinterpret_cast<const float4 *>(ellw_lds + slot * (p.seg_len + 4));
+          const float4 *wrow = reinterpret_cast<const float4 *>(ellw_lds + __mul24(slot, p.seg_len + 4));
           const float4 *p0 = reinterpret_cast<const float4 *>(wbase + first);
           const float4 *p1 = reinterpret_cast<const float4 *>(wbase + PSTR + first);
           const float4 *p2 = reinterpret_cast<const float4 *>(wbase + 2 * PSTR + first);
@@ -895,6 +895,7 @@ int32_t fast_tables_create(pds_stft_plan *plan, const double *window, const int3
   const char *off = std::getenv("PDS_STFT_GENERIC");
   if (off && off[0] == '1') return PDS_OK;
   if (d.frame_length > d.dft_size || d.frame_length <= d.dft_size / 2) return PDS_OK;
+  if (d.frame_shift >= (1 << 22)) return PDS_OK;  // the kernel forms g * S with a 24-bit multiply
   // fast_log() skips the denormal rescue: a floor below the normal range stays on the generic path
   if (d.use_log && !((float)d.log_floor >= 1.17549435e-38f)) return PDS_OK;
   if (d.num_filts > 32767) return PDS_OK;
