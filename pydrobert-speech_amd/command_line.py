@@ -143,14 +143,15 @@ class FeatureDirWriter:
                 for b in range(len(signals)):  # per-utterance stream, as the reference seeds torch
                     seg = packed[offsets[b] : offsets[b + 1]]
                     seg.copy_(Dither(pre.coeff, seed=self.seed + first_index + b).apply(seg))
-            elif k == len(self.pre) - 1 and self.computer is not None:
-                fused = pre.coeff  # rides along with the frame loads
+            elif k == len(self.pre) - 1 and getattr(self.computer, "fuses_preemphasis", False):
+                fused = pre.coeff  # rides along with the frame loads (STFT computers only)
             else:
                 packed = pre.apply_packed(packed, offsets[:-1], lengths)
         if self.computer is None:
             feats, rows = packed.reshape(-1, 1), offsets
         else:
-            feats, rows = self.computer.compute_packed(packed, offsets[:-1], lengths, preemphasis=fused)
+            kwargs = {"preemphasis": fused} if fused else {}
+            feats, rows = self.computer.compute_packed(packed, offsets[:-1], lengths, **kwargs)
         feats, rows = self._postprocess(feats, np.asarray(rows, dtype=np.int64))
         feats = feats.to(torch.float32).cpu()
         return [feats[rows[b] : rows[b + 1]].clone() for b in range(len(signals))]

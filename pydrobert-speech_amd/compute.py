@@ -221,6 +221,8 @@ class ShortTimeFourierTransformFrameComputer(LinearFilterBankFrameComputer):
     """
 
     aliases = {"stft"}
+    #: :func:`launch` / :func:`compute_packed` take a ``preemphasis`` coefficient (batch driver)
+    fuses_preemphasis = True
 
     def __init__(
         self,

@@ -140,9 +140,12 @@ int32_t upload(T **dst, const T *src, size_t count) {
   return PDS_OK;
 }
 
-// x[i] - c x[i-1] with the product rounded before the subtraction, as numpy evaluates the
-// reference's Preemphasize (pre.py:146): the samples a fused kernel frames are then bit-identical
-// to the separate pass.  (The multiply goes through asm so that -ffp-contract=fast cannot fuse it.)
+// x[i] - c x[i-1] in the signal's own precision, product rounded before the subtraction (the
+// multiply goes through asm so that -ffp-contract=fast cannot fuse it).  The reference's Preemphasize
+// (pre.py:140-149) and pre.hip's separate pass evaluate this in float64 and cast back, so for float64
+// signals the fused samples are bit-identical to theirs; for float32 signals the fused form uses
+// the float32 coefficient and float32 arithmetic and is within about one ulp per sample of them --
+// inside the feature tolerance (1e-4), not bit-identical.
 __device__ __forceinline__ float preemph_sample(float cur, float prev, float c) {
   float t;
   asm("v_mul_f32 %0, %1, %2" : "=v"(t) : "v"(c), "v"(prev));

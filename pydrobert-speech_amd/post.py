@@ -381,6 +381,41 @@ class Deltas(PostProcessor):
             )
         return self._device_filts[key]
 
+    def _apply_per_order(self, features, host, axis, target, on_gpu, in_dtype):
+        """:func:`apply` for pad modes whose samples are computed or depend on the pad width"""
+        torch = _native.require_device()
+        lib = _native.lib()
+        host = np.asarray(host, dtype=np.float64)
+        shape = host.shape
+        ndim = host.ndim
+        time = shape[axis]
+        outer = int(np.prod(shape[:axis], dtype=np.int64))
+        inner = int(np.prod(shape[axis + 1 :], dtype=np.int64))
+        statics = features if on_gpu else _to_device(np.asarray(features))
+        res_dtype = statics.dtype if on_gpu else None
+        pieces = [statics]
+        for filt in self._filts[1:]:
+            reach = (len(filt) - 1) // 2
+            widths = [(0, 0)] * ndim
+            widths[axis] = (reach, reach)
+            src = _to_device(np.pad(host, widths, self._pad_mode, **self._pad_kwargs))
+            d_filt = torch.from_numpy(np.ascontiguousarray(filt)).to(src.device)
+            d_offs = torch.tensor([0, len(filt)], dtype=torch.int32, device=src.device)
+            out = torch.empty((2,) + shape, dtype=torch.float64, device=src.device)
+            with torch.cuda.device(src.device):
+                rc = lib.pds_deltas_f64(
+                    src.data_ptr(), outer, time, inner, d_filt.data_ptr(), d_offs.data_ptr(), 1, 0, reach,
+                    out.data_ptr(), outer * time * inner, time * inner, inner, 1, _stream(torch, src),
+                )
+            _native.check(rc, "pds_deltas")
+            pieces.append(out[1])
+        if on_gpu:
+            pieces = [pieces[0]] + [p.to(res_dtype) for p in pieces[1:]]
+            return torch.cat(pieces, target) if self.concatenate else torch.stack(pieces, target)
+        # the reference casts every order back to the input dtype before concatenating
+        cast = [np.asarray(features)] + [p.cpu().numpy().astype(in_dtype) for p in pieces[1:]]
+        return np.concatenate(cast, target) if self.concatenate else np.stack(cast, target)
+
     def apply(self, features, axis: int = -1, in_place: bool = False):
         torch = _native.require_device()
         lib = _native.lib()
@@ -416,18 +451,27 @@ class Deltas(PostProcessor):
             return np.concatenate(pieces, target) if self.concatenate else np.stack(pieces, target)
         edge = self._pad_mode == "edge" and not self._pad_kwargs
         max_off = (len(self._filts[-1]) - 1) // 2
+        # modes that COPY samples from positions fixed relative to the signal's ends: padding once
+        # by the widest filter's reach gives every order the samples the reference's own, narrower
+        # padding would (post.py:470-483)
+        copies = (isinstance(self._pad_mode, str) and self._pad_mode in ("reflect", "symmetric", "wrap")
+                  and not self._pad_kwargs)
         if edge:
             if t is None:
                 t = _to_device(work)
             src = t.contiguous()
-        else:
-            # any other numpy.pad mode: pad on the host by the widest filter's reach (the
-            # reference pads each order by its own reach, post.py:478-483; position-based
-            # modes give the same samples either way)
+        elif copies:
             host = work if t is None else t.cpu().numpy()
             widths = [(0, 0)] * ndim
             widths[axis] = (max_off, max_off)
             src = _to_device(np.pad(host, widths, self._pad_mode, **self._pad_kwargs))
+        else:
+            # every other numpy.pad mode (linear_ramp, statistics, constants, odd reflection,
+            # callables): the padded samples are computed, in float64, and may depend on the pad
+            # width -- pad each order by its own reach on a float64 copy, one launch per order, as
+            # the reference does
+            return self._apply_per_order(features, work if t is None else t.cpu().numpy(), axis, target,
+                                         on_gpu, in_dtype)
         d_filts, d_offs = self._filters_on(src.device)
         direct = self.concatenate and ndim == 2 and target != axis
         if direct:

@@ -91,9 +91,11 @@ def assert_features_close(got, want, rtol, atol, what=""):
     assert got.shape == want.shape, (what, got.shape, want.shape)
     if got.size == 0:
         return
+    nan_got, nan_want = np.isnan(got), np.isnan(want)
+    assert (nan_got == nan_want).all(), (what, "NaN positions differ", np.argwhere(nan_got != nan_want)[:5].tolist())
     err = np.abs(got - want)
     tol = atol + rtol * np.abs(want)
-    bad = err > tol
+    bad = ~(err <= tol) & ~nan_want  # (a NaN compares false both ways: it must not pass as "close")
     assert not bad.any(), (
         what, int(bad.sum()), float(err.max()), np.argwhere(bad)[:5].tolist(),
         got[bad][:5].tolist(), want[bad][:5].tolist(),

@@ -131,3 +131,25 @@ def test_map_and_channel_errors(tmp_path, capsys):
     with pytest.raises(ValueError, match="Channel specified as 5"):
         signals_to_torch_feat_dir([str(m), str(tmp_path / "o"), "--channel", "5"])
     assert signals_to_torch_feat_dir([str(m), str(tmp_path / "o"), "--channel", "1"]) == 0
+
+
+@pytest.mark.parametrize("with_preemph", [False, True])
+def test_short_integration_computer_config(tmp_path, with_preemph):
+    """An "si" computer takes no fused pre-emphasis: the driver runs the separate pass for it"""
+    import torch
+
+    rng = np.random.default_rng(8)
+    map_path, sigs = write_corpus(str(tmp_path), rng, (4000, 2500, 3999))
+    out = str(tmp_path / "feats")
+    si_cfg = {"name": "si", "bank": {"name": "gabor", "scaling_function": "mel", "num_filts": 8},
+              "include_energy": True, "use_power": True}
+    argv = [map_path, json.dumps(si_cfg), out]
+    if with_preemph:
+        argv += ["--preprocess", json.dumps({"name": "preemph", "coeff": 0.9})]
+    assert signals_to_torch_feat_dir(argv) == 0
+    comp = alias_factory_subclass_from_arg(FrameComputer, dict(si_cfg))
+    for utt, x in sigs.items():
+        got = torch.load(os.path.join(out, utt + ".pt"), weights_only=True).numpy()
+        want = comp.compute_full(Preemphasize(0.9).apply(x) if with_preemph else x)
+        assert got.shape == want.shape, utt
+        assert np.allclose(got, want, rtol=2e-4, atol=2e-4), (utt, np.abs(got - want).max())

@@ -334,3 +334,40 @@ def test_stack_rows_matches_per_utterance_apply(nv, pad_mode):
     wide = torch.from_numpy(np.concatenate([feats, feats], 1)).cuda()
     got2, _ = st.apply_rows(wide[:, :F], rows)
     assert np.array_equal(got2.cpu().numpy(), got)
+
+
+def _ramp_to_first(vector, pad_width, iaxis, kwargs):
+    """the callable pad mode of tests/golden/make_golden_post2.py (values depend on the pad width)"""
+    lo, hi = pad_width
+    if lo:
+        vector[:lo] = vector[lo] * np.arange(lo, 0, -1) / (lo + 1)
+    if hi:
+        vector[-hi:] = vector[-hi - 1] + np.arange(1, hi + 1) * 0.25
+
+
+@pytest.mark.parametrize("name,kwargs", [
+    ("linear_ramp", dict(pad_mode="linear_ramp", end_values=(1.5, -2.0))),
+    ("mean_stat2", dict(pad_mode="mean", stat_length=2)),
+    ("maximum", dict(pad_mode="maximum")),
+    ("constant_tenth", dict(pad_mode="constant", constant_values=0.1)),
+    ("reflect_odd", dict(pad_mode="reflect", reflect_type="odd")),
+    ("symmetric", dict(pad_mode="symmetric")),
+    ("wrap", dict(pad_mode="wrap")),
+    ("callable", dict(pad_mode=_ramp_to_first)),
+])
+def test_deltas_pad_modes_match_reference_outputs(name, kwargs):
+    """Every order padded by its own reach, in float64 (reference post.py:470-483)"""
+    import os
+
+    import torch
+
+    from tests.conftest import GOLDEN
+
+    with np.load(os.path.join(GOLDEN, "post2.npz")) as z:
+        for dt, tol in (("f4", 1e-6), ("f8", 1e-12)):
+            x, want = z[f"in/{dt}"], z[f"out/{name}/{dt}"]
+            got = Deltas(2, context_window=2, target_axis=-1, **kwargs).apply(x, axis=0)
+            assert got.dtype == want.dtype and got.shape == want.shape
+            assert np.allclose(got, want, rtol=tol, atol=tol), (name, dt, np.abs(got - want).max())
+            on_gpu = Deltas(2, context_window=2, target_axis=-1, **kwargs).apply(torch.from_numpy(x).cuda(), axis=0)
+            assert on_gpu.is_cuda and np.allclose(on_gpu.cpu().numpy(), want, rtol=tol, atol=tol)

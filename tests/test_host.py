@@ -333,3 +333,16 @@ def test_widened_classes_have_no_cpu_path_either():
                  lambda: Dither().apply(np.zeros(10, dtype=np.float32))):
         with pytest.raises(_native.NativeError, match="no HIP device"):
             call()
+
+
+def test_parity_helper_sees_nan():
+    """A NaN in a kernel's output must fail the comparison (and a NaN the reference has must be there)"""
+    from tests.conftest import assert_features_close
+
+    assert_features_close([np.nan, 1.0], [np.nan, 1.0], 1e-4, 1e-5)
+    with pytest.raises(AssertionError):
+        assert_features_close([np.nan, 1.0], [0.5, 1.0], 1e-4, 1e-5)
+    with pytest.raises(AssertionError):
+        assert_features_close([0.5, 1.0], [np.nan, 1.0], 1e-4, 1e-5)
+    with pytest.raises(AssertionError):
+        assert_features_close([0.5, 1.1], [0.5, 1.0], 1e-4, 1e-5)
