@@ -38,6 +38,10 @@ struct FastTables {
   float *d_seg_w = nullptr;        // [seg_rounds * 64][seg_len + 4]
   int32_t *d_seg_meta = nullptr;   // [seg_rounds * 64] first bins, then [num_filts] first slot | segments << 16
   int seg_rounds = 0, seg_len = 0, seg_wfloats = 0, seg_meta_ints = 0;
+  // matrix-pipe front end (mfma_front.h; 32 x 16 geometry): device image of the tables, built for
+  // the kernel instantiation of `mf_rows` rows (0 = not built: PDS_STFT_FRONT=valu, other geometry)
+  float *d_mf_tab = nullptr;
+  int mf_rows = 0;
 };
 
 }  // namespace pds

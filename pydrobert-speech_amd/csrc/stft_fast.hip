@@ -35,6 +35,7 @@
 #include <vector>
 
 #include "fft_inlane.h"
+#include "mfma_front.h"
 #include "pds_internal.h"
 
 namespace pds {
@@ -88,6 +89,7 @@ struct FastParams {
   float log_floor, inv_L, preemph;
   int chunks_per_utt, num_utts;
   int waves;  // wavefronts per workgroup of this launch (<= MAXWAVES)
+  const float *mf_tab;  // matrix-pipe front end (MF instantiations): image of MfmaFrontTables
   int step_utts, step_chunks;  // (grid waves) / chunks_per_utt and (grid waves) % chunks_per_utt
 };
 
@@ -178,10 +180,22 @@ constexpr int USLOTS = 4;
 
 // SEG: the filter phase is the segmented walk for dense banks (its own instantiation: inside the
 // ELL kernel its registers cost the headline instantiation three spills)
-template <int N1, int N2, int NROWS, int MAXWAVES, int MINW, bool ELL_LDS, bool PRE, bool SEG = false>
+//
+// MF > 0: steps 1-3a (loads, window, N1-point real DFT) in the matrix-pipe form of mfma_front.h with
+// MF pair steps: a lane holds k-slot q = lane / 16 of every frame's 16 x 16 x 4 tiles instead of
+// one frame's samples, the N1-point DFT costs 2 (MF + 1) v_mfma_f32_16x16x4_f32 per frame on the
+// matrix pipe (which runs beside the vector pipe) instead of ~250 vector instructions per item, and
+// the lane twiddles and stores four output rows of each frame.  From the exchange on the kernel is
+// the same.  (16-lane geometries with N1 = 32.)
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+template <int N1, int N2, int NROWS, int MAXWAVES, int MINW, bool ELL_LDS, bool PRE, bool SEG = false, int MF = 0>
 __global__ __launch_bounds__(MAXWAVES * 64, MINW) void stft_wave_kernel(const FastParams p) {
   using G = WaveGeom<N1, N2, NROWS>;
   constexpr int N = G::N, COLS = G::COLS, NREG = G::NREG, RS = G::RS, NB = G::NB, PSTR = G::PSTR;
+  constexpr int MSLOTS = 2 * MF + 1;  // per-lane sample slots of a frame (MF)
+  static_assert(MF == 0 || (N2 == 16 && N1 == 32 && MF == mfma_front_steps(NROWS)), "matrix-pipe front end: 32 x 16");
+  static_assert(MF == 0 || 4 * MSLOTS * 64 <= G::EXCH_F2 * 2, "edge-frame gather reuses the exchange area");
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -207,15 +221,39 @@ __global__ __launch_bounds__(MAXWAVES * 64, MINW) void stft_wave_kernel(const Fa
   __syncthreads();
 
   // per-lane constants, loop invariant: window slice and inter-stage twiddles
-  float win[NROWS];
-  float twr[COLS], twi[COLS];
+  [[maybe_unused]] float win[MF ? 1 : NROWS];
+  [[maybe_unused]] float twr[MF ? 1 : COLS], twi[MF ? 1 : COLS];
+  // MF: window and byte offset of the lane's sample slots, A operands of the two chains, twiddles of
+  // the lane's four output rows
+  [[maybe_unused]] float mwin[MSLOTS], mare[MF + 1], maim[MF + 1], mtwr[4], mtwi[4];
+  [[maybe_unused]] unsigned moff[MSLOTS];
+  if constexpr (MF > 0) {
+    const float *tab = p.mf_tab;
 #pragma unroll
-  for (int n1 = 0; n1 < NROWS; ++n1) win[n1] = p.win_lane[r * N1 + n1];
+    for (int sl = 0; sl < MSLOTS; ++sl) {
+      mwin[sl] = tab[sl * 64 + lane];
+      moff[sl] = (unsigned)reinterpret_cast<const int *>(tab)[(MSLOTS + sl) * 64 + lane] * 4u;
+    }
 #pragma unroll
-  for (int k1 = 1; k1 <= NREG; ++k1) {
-    const float2 t = p.tw_lane[r * COLS + k1];
-    twr[k1] = t.x;
-    twi[k1] = t.y;
+    for (int t = 0; t <= MF; ++t) {
+      mare[t] = tab[(3 * MSLOTS + t) * 64 + lane];
+      maim[t] = tab[(3 * MSLOTS + MF + 1 + t) * 64 + lane];
+    }
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      const float2 t = reinterpret_cast<const float2 *>(tab + (3 * MSLOTS + 2 * (MF + 1)) * 64)[v * 64 + lane];
+      mtwr[v] = t.x;
+      mtwi[v] = t.y;
+    }
+  } else {
+#pragma unroll
+    for (int n1 = 0; n1 < NROWS; ++n1) win[n1] = p.win_lane[r * N1 + n1];
+#pragma unroll
+    for (int k1 = 1; k1 <= NREG; ++k1) {
+      const float2 t = p.tw_lane[r * COLS + k1];
+      twr[k1] = t.x;
+      twi[k1] = t.y;
+    }
   }
   const int L = p.L, S = p.S;
   const bool use_power = p.use_power != 0;
@@ -269,135 +307,288 @@ __global__ __launch_bounds__(MAXWAVES * 64, MINW) void stft_wave_kernel(const Fa
     }
     PDS_PHASE(0);
     const float *x = p.sig + sig_off;
-    // Common case, decided on scalars: all GROUPS frames exist and every row they read lies
-    // inside the signal.  Otherwise per-lane bookkeeping: lanes of a frame past the end
-    // recompute the last frame (their rows are never stored); frames touching a signal end are
-    // gathered with reflected indices (1: one bounce suffices, 2: general reflection).
     const int start0 = tb * S - p.pad_left;
     bool valid = true;
-    int start = start0 + __mul24(g, S);  // (24-bit multiplies issue at full rate, 32-bit ones at a quarter)
-    int wmode = 0;
-    if (!(tb + G::GROUPS <= nfr && start0 >= (PRE ? 1 : 0) &&
-          start0 + (G::GROUPS - 1) * S + NROWS * N2 <= n)) {
-      valid = tb + g < nfr;
-      start = (valid ? tb + g : nfr - 1) * S - p.pad_left;
-      int mode = 0;
-      // (with fused pre-emphasis the direct loads also read x[start - 1])
-      if (start < (PRE ? 1 : 0) || start + NROWS * N2 > n) mode = 1;
-      if (start < -n || start + L > 2 * n) mode = 2;
-      wmode = __builtin_amdgcn_readfirstlane(__any(mode == 2) ? 2 : (__any(mode == 1) ? 1 : 0));
-    }
-
+    float energy = 0.0f;
     // W_(2 N2)^r, twiddle of lane r in the distributed untangling of the even/odd-sum column:
     // re-read from LDS every iteration rather than held in two registers per lane -- the kernel
     // sits exactly at the 128-VGPR occupancy step
     const float2 sw = sw_lds[r];
-    float a[N1];
-    float energy = 0.0f;
-    if (wmode == 0) {
-      // Lanes past the frame's end in the last row read samples of the next frame; the
-      // window (exactly 0 there, applied with the 0 * x = 0 multiply) removes them.
-      const float *xp = x + (start + r);
+    [[maybe_unused]] float even_sum, odd_sum, Ar[COLS], Ai[COLS];  // (in-lane front end)
+    if constexpr (MF > 0) {
+      // ---- matrix-pipe front end (mfma_front.h).  Here a lane is (k-slot q = g, residue r) of
+      // EVERY frame of the item; frame starts are scalars.
+      int fstart[4];
 #pragma unroll
-      for (int n1 = 0; n1 < NROWS; ++n1) a[n1] = (PDS_ABLATE & 1) ? (float)(lane + n1) : xp[n1 * N2];
-      if constexpr (PRE) {
-        // predecessor of lane r's sample: lane r - 1 of the same row, or (r = 0) the last lane
-        // of the previous row.  With 16 lanes per frame a lane group is one DPP row and
-        // row_ror:1 delivers both; other group sizes load the predecessor.
-        if constexpr (N2 == 16) {
-          float carry = 0.0f;
-          if (r == 0) carry = xp[-1];
+      for (int fg = 0; fg < 4; ++fg) fstart[fg] = start0 + fg * S;
+      int wmode = 0;
+      if (!(tb + 4 <= nfr && start0 >= (PRE ? 1 : 0) && start0 + 3 * S + NROWS * 16 <= n)) {
+        // frames past the utterance's last one recompute the last frame (their rows are never
+        // stored); frames touching a signal end are gathered with reflected indices
+        valid = tb + g < nfr;
 #pragma unroll
-          for (int n1 = 0; n1 < NROWS; ++n1) {
-            const float rot = __int_as_float(__builtin_amdgcn_update_dpp(
-                0, __float_as_int(a[n1]), 0x121 /* row_ror:1 */, 0xf, 0xf, false));
-            const float prev = r == 0 ? carry : rot;
-            carry = rot;
-            a[n1] = preemph_sample(a[n1], prev, p.preemph);
-          }
-        } else {
-#pragma unroll
-          for (int n1 = 0; n1 < NROWS; ++n1) a[n1] = preemph_sample(a[n1], xp[n1 * N2 - 1], p.preemph);
+        for (int fg = 0; fg < 4; ++fg) {
+          const int st = (tb + fg < nfr ? tb + fg : nfr - 1) * S - p.pad_left;
+          fstart[fg] = st;
+          int mode = (st < (PRE ? 1 : 0) || st + NROWS * 16 > n) ? 1 : 0;
+          if (st < -n || st + L > 2 * n) mode = 2;
+          wmode = mode > wmode ? mode : wmode;
         }
       }
-    } else {
-      float *tmp = wbase;
-#pragma unroll 1
-      for (int n1 = 0; n1 < NROWS; ++n1) {
-        const int idx = n1 * N2 + r;
-        float v = 0.0f;
-        if (idx < L) {
-          int i = start + idx;
-          if (wmode == 1) {
-            i = i < 0 ? -1 - i : (i >= n ? 2 * n - 1 - i : i);
-          } else {
-            i = (int)reflect_index((int64_t)i, (int64_t)n);
+      float xs[4][MSLOTS];
+      if (wmode == 0) {
+#pragma unroll
+        for (int fg = 0; fg < 4; ++fg) {
+          // scalar frame base + the lane's 32-bit byte offset: no 64-bit vector arithmetic
+          const char *xg = reinterpret_cast<const char *>(x + fstart[fg]);
+#pragma unroll
+          for (int sl = 0; sl < MSLOTS; ++sl) {
+            float v = (PDS_ABLATE & 1) ? (float)(lane + sl) : *reinterpret_cast<const float *>(xg + moff[sl]);
+            if constexpr (PRE) v = preemph_sample(v, *reinterpret_cast<const float *>(xg + moff[sl] - 4), p.preemph);
+            xs[fg][sl] = v;
           }
-          v = x[i];
-          if (PRE && i > 0) v = preemph_sample(v, x[i - 1], p.preemph);
         }
-        tmp[n1 * 64 + lane] = v;
-      }
-      wave_sync();
-#pragma unroll
-      for (int n1 = 0; n1 < NROWS; ++n1) a[n1] = tmp[n1 * 64 + lane];
-      wave_sync();
-    }
-    if (p.include_energy) {
-      // compute.py:392-393, on the un-windowed samples of the frame proper
-      // Rows below N1/2 lie inside the frame (this kernel requires L > N/2); the others are
-      // masked against L.  The limit goes through an opaque asm so that the compares are made
-      // here, per item: hoisted out of the loop they would sit in one scalar register pair per
-      // row for the whole kernel.
-      int lim = L - r;
-      asm volatile("" : "+v"(lim));
-#pragma unroll
-      for (int n1 = 0; n1 < NROWS; ++n1) {
-        const float v = (n1 < N1 / 2 || n1 * N2 < lim) ? a[n1] : 0.0f;
-        energy = fmaf(v, v, energy);
-      }
-    }
-    PDS_PHASE(4);
-#pragma unroll
-    for (int n1 = 0; n1 < NROWS; ++n1) a[n1] = mul_legacy(a[n1], win[n1]);
-#pragma unroll
-    for (int n1 = NROWS; n1 < N1; ++n1) a[n1] = 0.0f;
-
-    float even_sum, odd_sum, Ar[COLS], Ai[COLS];
-    if constexpr (PDS_ABLATE & 2) {
-      even_sum = a[0];
-      odd_sum = a[1];
-#pragma unroll
-      for (int k = 0; k < COLS; ++k) {
-        Ar[k] = a[2 * k];
-        Ai[k] = a[2 * k + 1];
-      }
-    } else if constexpr (inl::is_pow2(N1)) {
-      inl::rdft_scaled<N1>(a, even_sum, odd_sum, Ar, Ai);
-    } else {
-      inl::rdft_direct<N1>(a, even_sum, odd_sum, Ar, Ai);
-    }
-
-    // transpose through LDS: row k1 of this frame's block holds column k1 for all n2; row 0
-    // holds c[j] = sum_q xw[j + 2 N2 q] (j < 2 N2), the input of the multiples of N1/2.  (Odd
-    // N1: c[j] = sum_q xw[j + N2 q] for j < N2 and zeros above, whose 2 N2-point transform has
-    // the multiples of N1 at its even outputs; the odd ones are not bins and are dropped.)
-    PDS_PHASE(1);
-    {
-      float *row0 = reinterpret_cast<float *>(exch);
-      row0[r] = even_sum;
-      row0[N2 + r] = odd_sum;
-    }
-#pragma unroll
-    for (int k1 = 1; k1 <= NREG; ++k1) {
-      float2 v;
-      v.x = Ar[k1] * twr[k1] - Ai[k1] * twi[k1];
-      v.y = Ar[k1] * twi[k1] + Ai[k1] * twr[k1];
-      if constexpr (PDS_ABLATE & 4) {
-        Ar[k1] = v.x;
-        Ai[k1] = v.y;
       } else {
-        exch[k1 * RS + r] = v;
+        float *tmp = wbase;
+        const int *offs = reinterpret_cast<const int *>(p.mf_tab) + MSLOTS * 64 + lane;
+#pragma unroll 1
+        for (int fg = 0; fg < 4; ++fg) {
+          const int st = fstart[fg];
+#pragma unroll 1
+          for (int sl = 0; sl < MSLOTS; ++sl) {
+            int i = st + offs[sl * 64];
+            if (wmode == 1) {
+              i = i < 0 ? -1 - i : (i >= n ? 2 * n - 1 - i : i);
+            } else {
+              i = (int)reflect_index((int64_t)i, (int64_t)n);
+            }
+            float v = x[i];
+            if (PRE && i > 0) v = preemph_sample(v, x[i - 1], p.preemph);
+            tmp[(fg * MSLOTS + sl) * 64 + lane] = v;
+          }
+        }
+        wave_sync();
+#pragma unroll
+        for (int fg = 0; fg < 4; ++fg)
+#pragma unroll
+          for (int sl = 0; sl < MSLOTS; ++sl) xs[fg][sl] = tmp[(fg * MSLOTS + sl) * 64 + lane];
+        wave_sync();
+      }
+      if (p.include_energy) {
+        // compute.py:392-393 on the un-windowed samples: a slot counts where it is a sample of the
+        // frame of its own (mask table); lane sums, then the 16 lanes of a row, then the four rows
+        const float *em = p.mf_tab + 2 * MSLOTS * 64 + lane;
+        float eg[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int sl = 0; sl < MSLOTS; ++sl) {
+          const float m = em[sl * 64];
+#pragma unroll
+          for (int fg = 0; fg < 4; ++fg) {
+            const float xm = mul_legacy(xs[fg][sl], m);
+            eg[fg] = fmaf(xm, xm, eg[fg]);
+          }
+        }
+#pragma unroll
+        for (int fg = 0; fg < 4; ++fg) {
+          float e = eg[fg];
+          e = dpp_add<0xB1>(e);   // quad_perm [1,0,3,2]
+          e = dpp_add<0x4E>(e);   // quad_perm [2,3,0,1]
+          e = dpp_add<0x141>(e);  // row_half_mirror
+          e = dpp_add<0x140>(e);  // row_mirror: every lane of a row holds the row's sum
+          const int ei = __float_as_int(e);
+          const float tot = (__int_as_float(__builtin_amdgcn_readlane(ei, 0)) +
+                             __int_as_float(__builtin_amdgcn_readlane(ei, 16))) +
+                            (__int_as_float(__builtin_amdgcn_readlane(ei, 32)) +
+                             __int_as_float(__builtin_amdgcn_readlane(ei, 48)));
+          if (g == fg) energy = tot;
+        }
+      }
+      PDS_PHASE(4);
+      float sv[4][MF], dv[4][MF], cv[4], uv[4];
+#pragma unroll
+      for (int fg = 0; fg < 4; ++fg) {
+        // (plain multiplies: a slot without a sample of its own re-reads a sample of the SAME frame
+        // with weight zero, so nothing from outside the frame can reach it)
+        cv[fg] = xs[fg][2 * MF] * mwin[2 * MF];
+        float u = cv[fg];
+#pragma unroll
+        for (int t = 0; t < MF; ++t) {
+          const float a = xs[fg][2 * t] * mwin[2 * t];
+          sv[fg][t] = fmaf(xs[fg][2 * t + 1], mwin[2 * t + 1], a);
+          dv[fg][t] = fmaf(-xs[fg][2 * t + 1], mwin[2 * t + 1], a);
+          u += sv[fg][t];
+        }
+        uv[fg] = u;
+      }
+      f32x4 accR[4], accI[4];
+#pragma unroll
+      for (int fg = 0; fg < 4; ++fg) {
+        accR[fg] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+        accI[fg] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+      }
+      if constexpr (!(PDS_ABLATE & 2)) {
+#pragma unroll
+        for (int t = 0; t < MF; ++t)
+#pragma unroll
+          for (int fg = 0; fg < 4; ++fg) {
+            accR[fg] = __builtin_amdgcn_mfma_f32_16x16x4f32(mare[t], sv[fg][t], accR[fg], 0, 0, 0);
+            accI[fg] = __builtin_amdgcn_mfma_f32_16x16x4f32(maim[t], dv[fg][t], accI[fg], 0, 0, 0);
+          }
+#pragma unroll
+        for (int fg = 0; fg < 4; ++fg) {
+          accR[fg] = __builtin_amdgcn_mfma_f32_16x16x4f32(mare[MF], cv[fg], accR[fg], 0, 0, 0);
+          accI[fg] = __builtin_amdgcn_mfma_f32_16x16x4f32(maim[MF], uv[fg], accI[fg], 0, 0, 0);
+        }
+      } else {
+#pragma unroll
+        for (int fg = 0; fg < 4; ++fg) {
+          accR[fg] = f32x4{sv[fg][0], sv[fg][1], sv[fg][2], cv[fg]};
+          accI[fg] = f32x4{dv[fg][0], dv[fg][1], dv[fg][2], uv[fg]};
+        }
+      }
+      // the lane's rows 4 q + v are columns k1 = 4 q + v + 1 of every frame; row 15 (q = 3, v = 3)
+      // holds the even / odd row sums, which go to row 0 of the frame's exchange block
+      PDS_PHASE(1);
+      float2 *mine = reinterpret_cast<float2 *>(wbase) + (4 * g + 1) * RS + r;
+      float *row0 = wbase + r;
+#pragma unroll
+      for (int fg = 0; fg < 4; ++fg) {
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+          float2 val;
+          val.x = accR[fg][v] * mtwr[v] - accI[fg][v] * mtwi[v];
+          val.y = accR[fg][v] * mtwi[v] + accI[fg][v] * mtwr[v];
+          if (v < 3 || g != 3) {
+            mine[fg * COLS * RS + v * RS] = val;
+          } else {
+            row0[fg * COLS * RS * 2] = accR[fg][3];
+            row0[fg * COLS * RS * 2 + 16] = accI[fg][3];
+          }
+        }
+      }
+    } else {
+      // Common case, decided on scalars: all GROUPS frames exist and every row they read lies
+      // inside the signal.  Otherwise per-lane bookkeeping: lanes of a frame past the end
+      // recompute the last frame (their rows are never stored); frames touching a signal end are
+      // gathered with reflected indices (1: one bounce suffices, 2: general reflection).
+      int start = start0 + __mul24(g, S);  // (24-bit multiplies issue at full rate, 32-bit ones at a quarter)
+      int wmode = 0;
+      if (!(tb + G::GROUPS <= nfr && start0 >= (PRE ? 1 : 0) &&
+            start0 + (G::GROUPS - 1) * S + NROWS * N2 <= n)) {
+        valid = tb + g < nfr;
+        start = (valid ? tb + g : nfr - 1) * S - p.pad_left;
+        int mode = 0;
+        // (with fused pre-emphasis the direct loads also read x[start - 1])
+        if (start < (PRE ? 1 : 0) || start + NROWS * N2 > n) mode = 1;
+        if (start < -n || start + L > 2 * n) mode = 2;
+        wmode = __builtin_amdgcn_readfirstlane(__any(mode == 2) ? 2 : (__any(mode == 1) ? 1 : 0));
+      }
+
+      float a[N1];
+      if (wmode == 0) {
+        // Lanes past the frame's end in the last row read samples of the next frame; the
+        // window (exactly 0 there, applied with the 0 * x = 0 multiply) removes them.
+        const float *xp = x + (start + r);
+#pragma unroll
+        for (int n1 = 0; n1 < NROWS; ++n1) a[n1] = (PDS_ABLATE & 1) ? (float)(lane + n1) : xp[n1 * N2];
+        if constexpr (PRE) {
+          // predecessor of lane r's sample: lane r - 1 of the same row, or (r = 0) the last lane
+          // of the previous row.  With 16 lanes per frame a lane group is one DPP row and
+          // row_ror:1 delivers both; other group sizes load the predecessor.
+          if constexpr (N2 == 16) {
+            float carry = 0.0f;
+            if (r == 0) carry = xp[-1];
+#pragma unroll
+            for (int n1 = 0; n1 < NROWS; ++n1) {
+              const float rot = __int_as_float(__builtin_amdgcn_update_dpp(
+                  0, __float_as_int(a[n1]), 0x121 /* row_ror:1 */, 0xf, 0xf, false));
+              const float prev = r == 0 ? carry : rot;
+              carry = rot;
+              a[n1] = preemph_sample(a[n1], prev, p.preemph);
+            }
+          } else {
+#pragma unroll
+            for (int n1 = 0; n1 < NROWS; ++n1) a[n1] = preemph_sample(a[n1], xp[n1 * N2 - 1], p.preemph);
+          }
+        }
+      } else {
+        float *tmp = wbase;
+#pragma unroll 1
+        for (int n1 = 0; n1 < NROWS; ++n1) {
+          const int idx = n1 * N2 + r;
+          float v = 0.0f;
+          if (idx < L) {
+            int i = start + idx;
+            if (wmode == 1) {
+              i = i < 0 ? -1 - i : (i >= n ? 2 * n - 1 - i : i);
+            } else {
+              i = (int)reflect_index((int64_t)i, (int64_t)n);
+            }
+            v = x[i];
+            if (PRE && i > 0) v = preemph_sample(v, x[i - 1], p.preemph);
+          }
+          tmp[n1 * 64 + lane] = v;
+        }
+        wave_sync();
+#pragma unroll
+        for (int n1 = 0; n1 < NROWS; ++n1) a[n1] = tmp[n1 * 64 + lane];
+        wave_sync();
+      }
+      if (p.include_energy) {
+        // compute.py:392-393, on the un-windowed samples of the frame proper
+        // Rows below N1/2 lie inside the frame (this kernel requires L > N/2); the others are
+        // masked against L.  The limit goes through an opaque asm so that the compares are made
+        // here, per item: hoisted out of the loop they would sit in one scalar register pair per
+        // row for the whole kernel.
+        int lim = L - r;
+        asm volatile("" : "+v"(lim));
+#pragma unroll
+        for (int n1 = 0; n1 < NROWS; ++n1) {
+          const float v = (n1 < N1 / 2 || n1 * N2 < lim) ? a[n1] : 0.0f;
+          energy = fmaf(v, v, energy);
+        }
+      }
+      PDS_PHASE(4);
+#pragma unroll
+      for (int n1 = 0; n1 < NROWS; ++n1) a[n1] = mul_legacy(a[n1], win[n1]);
+#pragma unroll
+      for (int n1 = NROWS; n1 < N1; ++n1) a[n1] = 0.0f;
+
+      if constexpr (PDS_ABLATE & 2) {
+        even_sum = a[0];
+        odd_sum = a[1];
+#pragma unroll
+        for (int k = 0; k < COLS; ++k) {
+          Ar[k] = a[2 * k];
+          Ai[k] = a[2 * k + 1];
+        }
+      } else if constexpr (inl::is_pow2(N1)) {
+        inl::rdft_scaled<N1>(a, even_sum, odd_sum, Ar, Ai);
+      } else {
+        inl::rdft_direct<N1>(a, even_sum, odd_sum, Ar, Ai);
+      }
+
+      // transpose through LDS: row k1 of this frame's block holds column k1 for all n2; row 0
+      // holds c[j] = sum_q xw[j + 2 N2 q] (j < 2 N2), the input of the multiples of N1/2.  (Odd
+      // N1: c[j] = sum_q xw[j + N2 q] for j < N2 and zeros above, whose 2 N2-point transform has
+      // the multiples of N1 at its even outputs; the odd ones are not bins and are dropped.)
+      PDS_PHASE(1);
+      {
+        float *row0 = reinterpret_cast<float *>(exch);
+        row0[r] = even_sum;
+        row0[N2 + r] = odd_sum;
+      }
+#pragma unroll
+      for (int k1 = 1; k1 <= NREG; ++k1) {
+        float2 v;
+        v.x = Ar[k1] * twr[k1] - Ai[k1] * twi[k1];
+        v.y = Ar[k1] * twi[k1] + Ai[k1] * twr[k1];
+        if constexpr (PDS_ABLATE & 4) {
+          Ar[k1] = v.x;
+          Ai[k1] = v.y;
+        } else {
+          exch[k1 * RS + r] = v;
+        }
       }
     }
     wave_sync();
@@ -545,12 +736,15 @@ __global__ __launch_bounds__(MAXWAVES * 64, MINW) void stft_wave_kernel(const Fa
     if (p.include_energy) {
       // sum over the frame's lanes with DPP butterflies (lanes 1^, 2^, 7-, 15- within the row);
       // every lane ends up with the total, lane 0 of the frame stores it (compute.py:392-398)
-      energy = dpp_add<0xB1>(energy);   // quad_perm [1,0,3,2]
-      energy = dpp_add<0x4E>(energy);   // quad_perm [2,3,0,1]
-      energy = dpp_add<0x141>(energy);  // row_half_mirror
-      if constexpr (N2 >= 16) energy = dpp_add<0x140>(energy);  // row_mirror
-      if constexpr (N2 >= 32) energy += __shfl_xor(energy, 16, 64);
-      if constexpr (N2 == 64) energy += __shfl_xor(energy, 32, 64);
+      // (the matrix-pipe front end has summed it already)
+      if constexpr (MF == 0) {
+        energy = dpp_add<0xB1>(energy);   // quad_perm [1,0,3,2]
+        energy = dpp_add<0x4E>(energy);   // quad_perm [2,3,0,1]
+        energy = dpp_add<0x141>(energy);  // row_half_mirror
+        if constexpr (N2 >= 16) energy = dpp_add<0x140>(energy);  // row_mirror
+        if constexpr (N2 >= 32) energy += __shfl_xor(energy, 16, 64);
+        if constexpr (N2 == 64) energy += __shfl_xor(energy, 32, 64);
+      }
       float e = energy * p.inv_L;
       if (!use_power) e = __builtin_amdgcn_sqrtf(e);
       if (p.use_log) e = fast_log(p.log_floor > e ? p.log_floor : e);
@@ -784,6 +978,7 @@ static int32_t launch_wave(const pds_stft_plan *plan, const BatchArgs &a) {
   if (pre && !in_lds) return launch_stft_generic_f32(plan, a);
   p.preemph = (float)a.preemph;
   p.waves = waves;
+  p.mf_tab = ft.d_mf_tab;
   const size_t smem = waves * per_wave + fixed + (in_lds ? table_bytes : 0);
   constexpr bool HAS_SEG = G::GROUPS == 4;
   const bool seg = HAS_SEG && p.seg_rounds > 0;
@@ -791,11 +986,23 @@ static int32_t launch_wave(const pds_stft_plan *plan, const BatchArgs &a) {
               : seg    ? stft_wave_kernel<N1, N2, NROWS, CU_WAVES, MINW, true, false, HAS_SEG>
               : in_lds ? stft_wave_kernel<N1, N2, NROWS, CU_WAVES, MINW, true, false>
                        : stft_wave_kernel<N1, N2, NROWS, CU_WAVES, MINW, false, false>;
+  // matrix-pipe front end: the 32 x 16 geometry with LDS-resident filter tables, when the plan has
+  // its tables for this row count
+  constexpr int MFS = (N1 == 32 && N2 == 16) ? mfma_front_steps(NROWS) : 0;
+  bool mf = false;
+  if constexpr (MFS > 0) {
+    if (in_lds && ft.d_mf_tab && ft.mf_rows == NROWS) {
+      mf = true;
+      kern = pre   ? stft_wave_kernel<N1, N2, NROWS, CU_WAVES, MINW, true, true, false, MFS>
+             : seg ? stft_wave_kernel<N1, N2, NROWS, CU_WAVES, MINW, true, false, HAS_SEG, MFS>
+                   : stft_wave_kernel<N1, N2, NROWS, CU_WAVES, MINW, true, false, false, MFS>;
+    }
+  }
   // the dynamic-LDS limit is an attribute of the kernel on one device: raised once per
   // (instantiation, device, variant) and remembered (relaxed atomics: a lost race repeats the call)
   constexpr int kDevices = 64;
-  static std::atomic<size_t> attr_smem[kDevices][4];
-  const int which = pre ? 2 : seg ? 3 : (in_lds ? 1 : 0);
+  static std::atomic<size_t> attr_smem[kDevices][8];
+  const int which = (pre ? 2 : seg ? 3 : (in_lds ? 1 : 0)) + (mf ? 4 : 0);
   const bool cached = plan->device >= 0 && plan->device < kDevices;
   if (!cached || smem > attr_smem[plan->device][which].load(std::memory_order_relaxed)) {
     PDS_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -825,6 +1032,11 @@ static int32_t launch_wave(const pds_stft_plan *plan, const BatchArgs &a) {
 
 int32_t launch_stft_fast_f32(const pds_stft_plan *plan, const BatchArgs &a) {
   const int rows = plan->fast.rows;
+#ifdef PDS_DEV_ONLY512  // (ISA inspection builds: the headline instantiations alone)
+  if (plan->fast.kind == 512 && rows <= 25) return launch_wave<32, 16, 25, 4>(plan, a);
+  set_error("stft_batch: development build");
+  return PDS_ERR_INVALID;
+#else
   switch (plan->fast.kind) {
     case 128:
       PDS_GEOM_ROWS(16, 8, 10, 4) PDS_GEOM_ROWS(16, 8, 13, 4) PDS_GEOM_ROWS(16, 8, 16, 4)
@@ -862,6 +1074,7 @@ int32_t launch_stft_fast_f32(const pds_stft_plan *plan, const BatchArgs &a) {
   }
   set_error("stft_batch: no fused kernel for this plan");
   return PDS_ERR_INVALID;
+#endif
 }
 #undef PDS_GEOM_ROWS
 
@@ -1059,6 +1272,33 @@ int32_t fast_tables_create(pds_stft_plan *plan, const double *window, const int3
     tws[2 * r + 1] = (float)std::sin(ang);
   }
   if (rc == PDS_OK) rc = upload(&ft.d_tw_special, tws.data(), tws.size());
+  // matrix-pipe front end (mfma_front.h): the 32 x 16 geometry, tables for the row count of the
+  // instantiation launch_stft_fast_f32 picks.  PDS_STFT_FRONT=valu keeps the in-lane transform.
+  {
+    const char *front = std::getenv("PDS_STFT_FRONT");
+    const int rows = (d.frame_length + n2 - 1) / n2;
+    int bucket = 0;
+    for (int b : {20, 25, 28, 30, 32})
+      if (!bucket && rows <= b) bucket = b;
+    MfmaFrontTables mt;
+    if (rc == PDS_OK && n1 == 32 && n2 == 16 && bucket && !(front && std::strcmp(front, "valu") == 0) &&
+        build_mfma_front(n1, bucket, d.frame_length, window, mt)) {
+      std::vector<float> image;
+      image.reserve(mt.words());
+      image.insert(image.end(), mt.win.begin(), mt.win.end());
+      for (int32_t v : mt.off) {
+        float f;
+        std::memcpy(&f, &v, sizeof f);
+        image.push_back(f);
+      }
+      image.insert(image.end(), mt.emask.begin(), mt.emask.end());
+      image.insert(image.end(), mt.a_re.begin(), mt.a_re.end());
+      image.insert(image.end(), mt.a_im.begin(), mt.a_im.end());
+      image.insert(image.end(), mt.tw.begin(), mt.tw.end());
+      rc = upload(&ft.d_mf_tab, image.data(), image.size());
+      ft.mf_rows = bucket;
+    }
+  }
   if (rc != PDS_OK) return rc;
   hipDeviceProp_t prop;
   PDS_HIP(hipGetDeviceProperties(&prop, plan->device));
@@ -1075,6 +1315,7 @@ void fast_tables_destroy(pds_stft_plan *plan) {
   (void)hipFree(ft.d_window);
   (void)hipFree(ft.d_twiddle);
   (void)hipFree(ft.d_tw_special);
+  (void)hipFree(ft.d_mf_tab);
   (void)hipFree(ft.d_seg_w);
   (void)hipFree(ft.d_seg_meta);
   (void)hipFree(ft.d_ell_w);
