@@ -38,6 +38,12 @@ struct FastTables {
   float *d_seg_w = nullptr;        // [seg_rounds * 64][seg_len + 4]
   int32_t *d_seg_meta = nullptr;   // [seg_rounds * 64] first bins, then [num_filts] first slot | segments << 16
   int seg_rounds = 0, seg_len = 0, seg_wfloats = 0, seg_meta_ints = 0;
+  // row-segment filter walk (rseg_tables.h; 16-lane geometries): 0 rounds = not built for this plan
+  float *d_rs_w = nullptr;         // [rs_rounds][rs_len / 4][64][4]
+  int32_t *d_rs_meta = nullptr;    // [rs_rounds * 64]
+  int rs_rounds = 0, rs_len = 0, rs_wfloats = 0;
+  int walk = 0;  // preferred filter walk: 0 ELL, 1 segments (dense banks), 2 row segments
+  long rs_reads = 0, rs_cost = 0, ell_reads = 0, seg_reads = 0;  // 16-byte LDS reads per lane and item of each walk
   // matrix-pipe front end (mfma_front.h; 32 x 16 geometry): device image of the tables, built for
   // the kernel instantiation of `mf_rows` rows (0 = not built: PDS_STFT_FRONT=valu, other geometry)
   float *d_mf_tab = nullptr;

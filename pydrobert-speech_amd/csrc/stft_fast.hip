@@ -30,12 +30,14 @@
 #include <algorithm>
 #include <atomic>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <vector>
 
 #include "fft_inlane.h"
 #include "mfma_front.h"
+#include "rseg_tables.h"
 #include "pds_internal.h"
 
 namespace pds {
@@ -62,6 +64,36 @@ namespace pds {
 #endif
 #ifndef PDS_ABLATE
 #define PDS_ABLATE 0
+#endif
+// Diagnostic builds (tools/build_variant.sh -DPDS_STAMPS=1, tools/phase_stamps.py): every wave adds up
+// the shader-clock time it spends in each phase of an item (s_memtime at the phase boundaries, with
+// the loads drained where a phase ends at their arrival) and leaves the sums in a buffer set through
+// pds_debug_set_stamp_buffer.  The stamps themselves cost ~10 %; 0 in the product build.
+#ifndef PDS_STAMPS
+#define PDS_STAMPS 0
+#endif
+#if PDS_STAMPS
+static unsigned long long *g_stamp_buf = nullptr;
+extern "C" __attribute__((visibility("default"))) void pds_debug_set_stamp_buffer(unsigned long long *d_buf) {
+  g_stamp_buf = d_buf;
+}
+#define PDS_STAMP(i, drain)                                               \
+  do {                                                                    \
+    __builtin_amdgcn_sched_barrier(0);                                    \
+    if (drain) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           \
+    const unsigned long long now_ = __builtin_readcyclecounter();         \
+    st_acc[i] += now_ - st_prev;                                          \
+    st_prev = now_;                                                       \
+    __builtin_amdgcn_sched_barrier(0);                                    \
+  } while (0)
+#else
+#define PDS_STAMP(i, drain) do { } while (0)
+#endif
+// Experiment (tools/build_variant.sh -DPDS_STAGGER=1): the second half of a workgroup's waves (the SIMD
+// partners of the first half) runs half an item behind, held there by two workgroup barriers per item,
+// so that one partner's transform phase runs beside the other's filter phase.
+#ifndef PDS_STAGGER
+#define PDS_STAGGER 0
 #endif
 #ifndef PDS_FILTER_UNROLL
 #define PDS_FILTER_UNROLL 2
@@ -90,6 +122,7 @@ struct FastParams {
   int chunks_per_utt, num_utts;
   int waves;  // wavefronts per workgroup of this launch (<= MAXWAVES)
   const float *mf_tab;  // matrix-pipe front end (MF instantiations): image of MfmaFrontTables
+  unsigned long long *stamps;  // diagnostic builds (PDS_STAMPS): [grid waves][8] phase times, else null
   int step_utts, step_chunks;  // (grid waves) / chunks_per_utt and (grid waves) % chunks_per_utt
 };
 
@@ -189,13 +222,20 @@ constexpr int USLOTS = 4;
 // the same.  (16-lane geometries with N1 = 32.)
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-template <int N1, int N2, int NROWS, int MAXWAVES, int MINW, bool ELL_LDS, bool PRE, bool SEG = false, int MF = 0>
+//
+// RSG: the filter phase is the row-segment walk of rseg_tables.h (power spectra bin-major in LDS,
+// a lane = one segment of one filter for all four frames; 16-lane geometries, tables in LDS)
+template <int N1, int N2, int NROWS, int MAXWAVES, int MINW, bool ELL_LDS, bool PRE, bool SEG = false, int MF = 0,
+          bool RSG = false>
 __global__ __launch_bounds__(MAXWAVES * 64, MINW) void stft_wave_kernel(const FastParams p) {
   using G = WaveGeom<N1, N2, NROWS>;
   constexpr int N = G::N, COLS = G::COLS, NREG = G::NREG, RS = G::RS, NB = G::NB, PSTR = G::PSTR;
   constexpr int MSLOTS = 2 * MF + 1;  // per-lane sample slots of a frame (MF)
   static_assert(MF == 0 || (N2 == 16 && N1 == 32 && MF == mfma_front_steps(NROWS)), "matrix-pipe front end: 32 x 16");
   static_assert(MF == 0 || 4 * MSLOTS * 64 <= G::EXCH_F2 * 2, "edge-frame gather reuses the exchange area");
+  constexpr int NBP = (NB + 3) / 4 * 4;  // RSG: bins kept in LDS (bin NBP = dump slot), as build_rseg sizes them
+  static_assert(!RSG || (G::GROUPS == 4 && ELL_LDS && !SEG && (NBP + 1) * 4 <= G::EXCH_F2 * 2),
+                "row-segment walk: four frames per wave, tables in LDS");
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -288,6 +328,11 @@ __global__ __launch_bounds__(MAXWAVES * 64, MINW) void stft_wave_kernel(const Fa
     sig_off = load_const(p.offsets + b);
     out_row = load_const(p.row_off + b);
   }
+  if constexpr (PDS_STAGGER) {
+    if (b < p.num_utts && (wave & 4)) __builtin_amdgcn_s_barrier();
+  }
+  [[maybe_unused]] unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  [[maybe_unused]] unsigned long long st_prev = PDS_STAMPS ? __builtin_readcyclecounter() : 0;
   while (b < p.num_utts) {
     int nchunk = chunk + p.step_chunks, nb = b + p.step_utts;
     if (nchunk >= p.chunks_per_utt) {
@@ -305,6 +350,8 @@ __global__ __launch_bounds__(MAXWAVES * 64, MINW) void stft_wave_kernel(const Fa
       out_row = load_const(p.row_off + pb);
       continue;
     }
+    PDS_STAMP(7, 0);  // item bookkeeping (and whatever the previous item left undrained)
+    if constexpr (PDS_STAMPS) ++st_acc[6];
     PDS_PHASE(0);
     const float *x = p.sig + sig_off;
     const int start0 = tb * S - p.pad_left;
@@ -403,6 +450,8 @@ __global__ __launch_bounds__(MAXWAVES * 64, MINW) void stft_wave_kernel(const Fa
           if (g == fg) energy = tot;
         }
       }
+      PDS_STAMP(0, 0);  // frame loads issued
+      PDS_STAMP(1, 1);  // ... and arrived
       PDS_PHASE(4);
       float sv[4][MF], dv[4][MF], cv[4], uv[4];
 #pragma unroll
@@ -548,6 +597,8 @@ __global__ __launch_bounds__(MAXWAVES * 64, MINW) void stft_wave_kernel(const Fa
           energy = fmaf(v, v, energy);
         }
       }
+      PDS_STAMP(0, 0);  // frame loads issued
+      PDS_STAMP(1, 1);  // ... and arrived
       PDS_PHASE(4);
 #pragma unroll
       for (int n1 = 0; n1 < NROWS; ++n1) a[n1] = mul_legacy(a[n1], win[n1]);
@@ -591,6 +642,8 @@ __global__ __launch_bounds__(MAXWAVES * 64, MINW) void stft_wave_kernel(const Fa
         }
       }
     }
+    PDS_STAMP(2, 0);  // window, N1-point transform, twiddles, exchange stores issued
+    if constexpr (PDS_STAGGER) __builtin_amdgcn_s_barrier();
     wave_sync();
 
     float pw[G::CPL][N2 + 1];
@@ -688,22 +741,30 @@ __global__ __launch_bounds__(MAXWAVES * 64, MINW) void stft_wave_kernel(const Fa
     // fetched here so that the P stores below cover the latency.  (Scalar loads return out of
     // order, so a wait for one is a wait for all: they are issued in two batches per item, this
     // one and the next item's record at the start of the filter phase.)
-    const Int4 lens4 = load_const(reinterpret_cast<const Int4 *>(p.ell_len));
-    const Int4 woff4 = load_const(reinterpret_cast<const Int4 *>(p.ell_woff));
+    Int4 lens4 = {0, 0, 0, 0}, woff4 = {0, 0, 0, 0};
+    if constexpr (!RSG && !SEG) {
+      lens4 = load_const(reinterpret_cast<const Int4 *>(p.ell_len));
+      woff4 = load_const(reinterpret_cast<const Int4 *>(p.ell_woff));
+    }
     const int slot_len[USLOTS] = {lens4.x, lens4.y, lens4.z, lens4.w};
     const int slot_woff[USLOTS] = {woff4.x, woff4.y, woff4.z, woff4.w};
     static_assert(USLOTS == 4, "slot tables are fetched as one int4 each");
     // every lane is done with the exchange area (same wave, in order): reuse it as P
+    PDS_STAMP(3, 0);  // exchange reads, N2-point transforms, power spectrum
     wave_sync();
     // Stores below avoid lane predicates (each costs exec-mask bookkeeping on the scalar unit):
     // lanes without a value of their own write to a padding slot that is zeroed afterwards.
+    // P[frame][bin] (row stride PSTR), or bin-major P[bin][frame] for the row-segment walk
+    float *const Pw = RSG ? wbase + g : Pg;           // the lane's frame
+    constexpr int PB = RSG ? 4 : 1;                   // floats per bin step
+    constexpr int PDUMP = RSG ? NBP : PSTR - 1;       // bin index of the padding slot
 #pragma unroll
     for (int q = 0; q < G::CPL; ++q) {
       const int kk = q * N2 + r;
       if (!G::DIST && q == 0 && r == 0) {
         // output m of the 2 N2-point transform is bin m N1 / 2 (odd N1: even m only)
 #pragma unroll
-        for (int m = 0; m <= N2; m += (N1 % 2 ? 2 : 1)) Pg[m * N1 / 2] = pw[q][m];
+        for (int m = 0; m <= N2; m += (N1 % 2 ? 2 : 1)) Pw[(m * N1 / 2) * PB] = pw[q][m];
       } else {
         // (DIST: lane 0 of q = 0 writes its meaningless column to multiples of N1, all of which
         // the special bins written next overwrite).  Lanes beyond the last column (only when the
@@ -713,21 +774,26 @@ __global__ __launch_bounds__(MAXWAVES * 64, MINW) void stft_wave_kernel(const Fa
         for (int k2 = 0; k2 < N2; ++k2) {
           // bin kk + N1*k2, or its mirror image when beyond N/2
           const int bin = (k2 < N2 / 2) ? kk + N1 * k2 : N - kk - N1 * k2;
-          Pg[live ? bin : PSTR - 1] = pw[q][k2];
+          Pw[(live ? bin : PDUMP) * PB] = pw[q][k2];
         }
       }
     }
     if constexpr (G::DIST) {
       // output m of the 2 N2-point transform is bin m N1 / 2 (odd N1: even m only)
       const bool has = r <= N2 / 2 && (N1 % 2 == 0 || r % 2 == 0);
-      Pg[has ? r * N1 / 2 : PSTR - 1] = sp0;
-      Pg[has ? (N2 - r) * N1 / 2 : PSTR - 1] = sp1;
+      Pw[(has ? r * N1 / 2 : PDUMP) * PB] = sp0;
+      Pw[(has ? (N2 - r) * N1 / 2 : PDUMP) * PB] = sp1;
     }
     // slots past the last bin are read (with weight 0) by the filter walk: keep them finite
+    if constexpr (RSG) {
+      constexpr int PADF = (NBP - NB) * 4;  // 4 .. 12 floats behind the last bin
+      wbase[NB * 4 + (lane < PADF ? lane : PADF - 1)] = 0.0f;
+    } else {
 #pragma unroll
-    for (int j0 = 0; j0 < PSTR - NB; j0 += N2) {
-      const int j = j0 + r;
-      Pg[NB + (j < PSTR - NB ? j : PSTR - NB - 1)] = 0.0f;
+      for (int j0 = 0; j0 < PSTR - NB; j0 += N2) {
+        const int j = j0 + r;
+        Pg[NB + (j < PSTR - NB ? j : PSTR - NB - 1)] = 0.0f;
+      }
     }
     // ---- filter bank: lane (g, r) integrates one filter per slot
     // scalar row base + a 32-bit lane offset: no 64-bit vector arithmetic per store
@@ -750,10 +816,13 @@ __global__ __launch_bounds__(MAXWAVES * 64, MINW) void stft_wave_kernel(const Fa
       if (p.use_log) e = fast_log(p.log_floor > e ? p.log_floor : e);
       if (valid && r == 0) obase[lane_off - col0] = e;
     }
+    PDS_STAMP(4, 0);  // P stores, energy
     PDS_PHASE(3);
-    int metas[USLOTS];  // first bin of the lane's row | (filter + 1) << 16, per slot
+    int metas[USLOTS] = {0};  // first bin of the lane's row | (filter + 1) << 16, per slot
+    if constexpr (!RSG && !SEG) {
 #pragma unroll
-    for (int sl = 0; sl < USLOTS; ++sl) metas[sl] = meta_lds[sl * N2 + r];
+      for (int sl = 0; sl < USLOTS; ++sl) metas[sl] = meta_lds[sl * N2 + r];
+    }
     wave_sync();
     [[maybe_unused]] const int frames_here = nfr - tb;  // frames of this chunk that exist (SEG)
     // this item's record is dead from here on: fetch the next one under the filter phase
@@ -810,6 +879,80 @@ __global__ __launch_bounds__(MAXWAVES * 64, MINW) void stft_wave_kernel(const Fa
           *reinterpret_cast<float *>(reinterpret_cast<char *>(obase) + byte_off) = acc;
       }
     };
+    if constexpr (RSG) {
+      // Row-segment walk (rseg_tables.h): lane = one segment of seg_len bins of one filter, for all
+      // four frames; weights [round][seg_len / 4][lane] float4, powers bin-major.
+      const float4 *P4 = reinterpret_cast<const float4 *>(wbase);
+      const int t4n = p.seg_len >> 2;
+      for (int rd = 0; rd < p.seg_rounds; ++rd) {
+        const int meta = meta_lds[rd * 64 + lane];
+        const float4 *prow = P4 + (meta & 0x3fff);
+        const float4 *wrow = reinterpret_cast<const float4 *>(ellw_lds) + __mul24(rd, t4n) * 64 + lane;
+        float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
+        auto quad = [&](int t4) {
+          const float4 w = wrow[t4 * 64];
+          const float4 x0 = prow[4 * t4], x1 = prow[4 * t4 + 1], x2 = prow[4 * t4 + 2], x3 = prow[4 * t4 + 3];
+          a0 = fmaf(w.x, x0.x, a0);
+          a1 = fmaf(w.x, x0.y, a1);
+          a2 = fmaf(w.x, x0.z, a2);
+          a3 = fmaf(w.x, x0.w, a3);
+          a0 = fmaf(w.y, x1.x, a0);
+          a1 = fmaf(w.y, x1.y, a1);
+          a2 = fmaf(w.y, x1.z, a2);
+          a3 = fmaf(w.y, x1.w, a3);
+          a0 = fmaf(w.z, x2.x, a0);
+          a1 = fmaf(w.z, x2.y, a1);
+          a2 = fmaf(w.z, x2.z, a2);
+          a3 = fmaf(w.z, x2.w, a3);
+          a0 = fmaf(w.w, x3.x, a0);
+          a1 = fmaf(w.w, x3.y, a1);
+          a2 = fmaf(w.w, x3.z, a2);
+          a3 = fmaf(w.w, x3.w, a3);
+        };
+        // the common segment lengths run unrolled, every read of the segment in flight at once
+        if (t4n == 3) {
+          quad(0);
+          quad(1);
+          quad(2);
+        } else if (t4n == 1) {
+          quad(0);
+        } else if (t4n == 2) {
+          quad(0);
+          quad(1);
+        } else {
+#pragma unroll 2
+          for (int t4 = 0; t4 < t4n; ++t4) quad(t4);
+        }
+        // add up a filter's segments (at most four, on consecutive lanes of one DPP row): lane i takes
+        // lane i + 1's sums where the table says the run continues, then lane i + 2's
+        const float m1 = (meta & (1 << 14)) ? 1.0f : 0.0f, m2 = (meta & (1 << 15)) ? 1.0f : 0.0f;
+        auto shl = [](float v, auto ctrl) {
+          return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), decltype(ctrl)::value, 0xf, 0xf, true));
+        };
+        a0 = fmaf(shl(a0, inl::Int<0x101>{}), m1, a0);
+        a1 = fmaf(shl(a1, inl::Int<0x101>{}), m1, a1);
+        a2 = fmaf(shl(a2, inl::Int<0x101>{}), m1, a2);
+        a3 = fmaf(shl(a3, inl::Int<0x101>{}), m1, a3);
+        a0 = fmaf(shl(a0, inl::Int<0x102>{}), m2, a0);
+        a1 = fmaf(shl(a1, inl::Int<0x102>{}), m2, a1);
+        a2 = fmaf(shl(a2, inl::Int<0x102>{}), m2, a2);
+        a3 = fmaf(shl(a3, inl::Int<0x102>{}), m2, a3);
+        const int f = (meta >> 16) - 1;  // the filter, on the first lane of its run; -1 elsewhere
+        const float vals[4] = {a0, a1, a2, a3};
+        float *dst = obase + col0 + (f < 0 ? 0 : f);
+#pragma unroll
+        for (int gg = 0; gg < 4; ++gg) {
+          float v = vals[gg];
+          // max(val, floor) as Python evaluates it: a NaN stays a NaN (compute.py:459)
+          if (p.use_log) v = fast_log(p.log_floor > v ? p.log_floor : v);
+          if (f >= 0 && gg < frames_here) dst[(int64_t)gg * p.out_stride] = v;
+        }
+      }
+      PDS_STAMP(5, 0);  // filter walk
+      if constexpr (PDS_STAGGER) __builtin_amdgcn_s_barrier();
+      wave_sync();
+      continue;
+    }
     if constexpr (SEG) {
       static_assert(!SEG || (G::GROUPS == 4 && ELL_LDS), "segmented walk: four frames per wave, tables in LDS");
       {
@@ -876,6 +1019,8 @@ __global__ __launch_bounds__(MAXWAVES * 64, MINW) void stft_wave_kernel(const Fa
             if (gg < frames_here) obase[(int64_t)gg * p.out_stride + col0 + f] = v;
           }
         }
+        PDS_STAMP(5, 0);  // filter walk
+      if constexpr (PDS_STAGGER) __builtin_amdgcn_s_barrier();
         wave_sync();
         continue;
       }
@@ -885,7 +1030,16 @@ __global__ __launch_bounds__(MAXWAVES * 64, MINW) void stft_wave_kernel(const Fa
       if (sl < p.ell_slots) run_slot(metas[sl], slot_len[sl], slot_woff[sl]);
     for (int sl = USLOTS; sl < p.ell_slots; ++sl)
       run_slot(meta_lds[sl * N2 + r], load_const(p.ell_len + sl), load_const(p.ell_woff + sl));
+    PDS_STAMP(5, 0);  // filter walk
+      if constexpr (PDS_STAGGER) __builtin_amdgcn_s_barrier();
     wave_sync();
+  }
+  if constexpr (PDS_STAMPS) {
+    if (p.stamps && lane == 0) {
+      unsigned long long *dst = p.stamps + ((size_t)blockIdx.x * p.waves + wave) * 8;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) dst[i] = st_acc[i];
+    }
   }
 }
 
@@ -940,20 +1094,23 @@ static int32_t launch_wave(const pds_stft_plan *plan, const BatchArgs &a) {
   const int shapes[4][2] = {{CU_WAVES / 2, 2}, {CU_WAVES, 1}, {CU_WAVES * 3 / 4, 1}, {CU_WAVES * 5 / 8, 1}};
   int waves = CU_WAVES / 2, wgs_per_cu = 2;
   bool in_lds = false;
-  // the segmented filter walk (dense banks) when its tables were built and fit in LDS; else the
-  // ELL walk
+  // Filter walk: the plan's preferred one (fast_tables_create: fewest 16-byte LDS reads per item, or
+  // PDS_STFT_WALK) when its tables fit in LDS beside the waves' areas, else the next: row segments
+  // (2), segments of dense banks (1), ELL (0; its tables may also stay in global memory).
   p.seg_rounds = 0;
   p.seg_len = 0;
   p.num_filts = plan->d.num_filts;
   const bool pre = a.preemph != 0.0;
-  // (no segmented variant of the fused pre-emphasis kernel: that combination takes the ELL walk)
-  for (int seg = (G::GROUPS == 4 && ft.seg_rounds > 0 && !pre) ? 1 : 0; seg >= 0 && !in_lds; --seg) {
-    const int meta_ints = seg ? ft.seg_meta_ints : ft.ell_slots * N2;
+  int walk = 0;
+  for (int cand = (G::GROUPS == 4) ? ft.walk : 0; cand >= 0 && !in_lds; --cand) {
+    // (no segmented variant of the fused pre-emphasis kernel)
+    if ((cand == 2 && ft.rs_rounds == 0) || (cand == 1 && (ft.seg_rounds == 0 || pre))) continue;
+    const int meta_ints = cand == 2 ? ft.rs_rounds * 64 : cand == 1 ? ft.seg_meta_ints : ft.ell_slots * N2;
     const int meta_pad = (std::max(meta_ints, USLOTS * N2) + 3) / 4 * 4;
     const size_t fixed = (size_t)N2 * 8 + (size_t)meta_pad * 4;
-    const size_t table_bytes = (size_t)(seg ? ft.seg_wfloats : ft.ell_wfloats) * 4;
+    const size_t table_bytes = (size_t)(cand == 2 ? ft.rs_wfloats : cand == 1 ? ft.seg_wfloats : ft.ell_wfloats) * 4;
     // (segment sums live behind P in the wave's area)
-    if (seg && (size_t)G::GROUPS * G::PSTR * 4 + (size_t)ft.seg_rounds * 64 * 16 > per_wave) continue;
+    if (cand == 1 && (size_t)G::GROUPS * G::PSTR * 4 + (size_t)ft.seg_rounds * 64 * 16 > per_wave) continue;
     for (const auto &shape : shapes)
       if (shape[0] * per_wave + fixed + table_bytes <= lds_cu / shape[1]) {
         waves = shape[0];
@@ -963,14 +1120,24 @@ static int32_t launch_wave(const pds_stft_plan *plan, const BatchArgs &a) {
       }
     p.ell_meta_pad = meta_pad;
     p.ell_meta_ints = meta_ints;
-    if (in_lds && seg) {
+    if (in_lds && cand == 1) {
       p.ell_w = ft.d_seg_w;
       p.ell_meta = ft.d_seg_meta;
       p.ell_wfloats = ft.seg_wfloats;
       p.seg_rounds = ft.seg_rounds;
       p.seg_len = ft.seg_len;
+    } else if (in_lds && cand == 2) {
+      p.ell_w = ft.d_rs_w;
+      p.ell_meta = ft.d_rs_meta;
+      p.ell_wfloats = ft.rs_wfloats;
+      p.seg_rounds = ft.rs_rounds;
+      p.seg_len = ft.rs_len;
     }
+    if (in_lds) walk = cand;
   }
+#ifdef PDS_FORCE_WAVES  // (experiment: throughput against resident waves per CU, two workgroups per CU)
+  if (in_lds && PDS_FORCE_WAVES <= CU_WAVES / 2) waves = PDS_FORCE_WAVES, wgs_per_cu = 2;
+#endif
   const size_t fixed = (size_t)N2 * 8 + (size_t)p.ell_meta_pad * 4;
   const size_t table_bytes = (size_t)p.ell_wfloats * 4;
   // the fused pre-emphasis variant exists for LDS-resident tables only; the rare other case
@@ -979,11 +1146,18 @@ static int32_t launch_wave(const pds_stft_plan *plan, const BatchArgs &a) {
   p.preemph = (float)a.preemph;
   p.waves = waves;
   p.mf_tab = ft.d_mf_tab;
+#if PDS_STAMPS
+  p.stamps = g_stamp_buf;
+#else
+  p.stamps = nullptr;
+#endif
   const size_t smem = waves * per_wave + fixed + (in_lds ? table_bytes : 0);
-  constexpr bool HAS_SEG = G::GROUPS == 4;
-  const bool seg = HAS_SEG && p.seg_rounds > 0;
-  auto kern = pre      ? stft_wave_kernel<N1, N2, NROWS, CU_WAVES, MINW, true, true>
-              : seg    ? stft_wave_kernel<N1, N2, NROWS, CU_WAVES, MINW, true, false, HAS_SEG>
+  constexpr bool W4 = G::GROUPS == 4;  // the walks over four frames exist for the 16-lane geometries
+  const bool seg = W4 && walk == 1, rsg = W4 && walk == 2;
+  auto kern = pre      ? (rsg ? stft_wave_kernel<N1, N2, NROWS, CU_WAVES, MINW, true, true, false, 0, W4>
+                              : stft_wave_kernel<N1, N2, NROWS, CU_WAVES, MINW, true, true>)
+              : rsg    ? stft_wave_kernel<N1, N2, NROWS, CU_WAVES, MINW, true, false, false, 0, W4>
+              : seg    ? stft_wave_kernel<N1, N2, NROWS, CU_WAVES, MINW, true, false, W4>
               : in_lds ? stft_wave_kernel<N1, N2, NROWS, CU_WAVES, MINW, true, false>
                        : stft_wave_kernel<N1, N2, NROWS, CU_WAVES, MINW, false, false>;
   // matrix-pipe front end: the 32 x 16 geometry with LDS-resident filter tables, when the plan has
@@ -993,16 +1167,18 @@ static int32_t launch_wave(const pds_stft_plan *plan, const BatchArgs &a) {
   if constexpr (MFS > 0) {
     if (in_lds && ft.d_mf_tab && ft.mf_rows == NROWS) {
       mf = true;
-      kern = pre   ? stft_wave_kernel<N1, N2, NROWS, CU_WAVES, MINW, true, true, false, MFS>
-             : seg ? stft_wave_kernel<N1, N2, NROWS, CU_WAVES, MINW, true, false, HAS_SEG, MFS>
+      kern = pre   ? (rsg ? stft_wave_kernel<N1, N2, NROWS, CU_WAVES, MINW, true, true, false, MFS, W4>
+                          : stft_wave_kernel<N1, N2, NROWS, CU_WAVES, MINW, true, true, false, MFS>)
+             : rsg ? stft_wave_kernel<N1, N2, NROWS, CU_WAVES, MINW, true, false, false, MFS, W4>
+             : seg ? stft_wave_kernel<N1, N2, NROWS, CU_WAVES, MINW, true, false, W4, MFS>
                    : stft_wave_kernel<N1, N2, NROWS, CU_WAVES, MINW, true, false, false, MFS>;
     }
   }
   // the dynamic-LDS limit is an attribute of the kernel on one device: raised once per
   // (instantiation, device, variant) and remembered (relaxed atomics: a lost race repeats the call)
   constexpr int kDevices = 64;
-  static std::atomic<size_t> attr_smem[kDevices][8];
-  const int which = (pre ? 2 : seg ? 3 : (in_lds ? 1 : 0)) + (mf ? 4 : 0);
+  static std::atomic<size_t> attr_smem[kDevices][12];
+  const int which = (pre ? (rsg ? 5 : 2) : rsg ? 4 : seg ? 3 : (in_lds ? 1 : 0)) + (mf ? 6 : 0);
   const bool cached = plan->device >= 0 && plan->device < kDevices;
   if (!cached || smem > attr_smem[plan->device][which].load(std::memory_order_relaxed)) {
     PDS_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1210,6 +1386,7 @@ int32_t fast_tables_create(pds_stft_plan *plan, const double *window, const int3
   if (n2 == 16 && d.num_filts > 0 && d.num_filts <= 65535) {
     long ell_reads = 0;
     for (int sl = 0; sl < slots; ++sl) ell_reads += 2L * (ell_len[sl] / 4);  // per item (the 64 lanes cover 4 frames)
+    ft.ell_reads = ell_reads;
     const int free_slots = ((n1 / 2) * (n2 + 2) * 4 * 2 - 4 * pstr) / 4;  // float4 slots behind P
     int best_len = 0, best_rounds = 0;
     long best_reads = 0;
@@ -1250,6 +1427,7 @@ int32_t fast_tables_create(pds_stft_plan *plan, const double *window, const int3
         }
       }
       if (ok) {
+        ft.seg_reads = best_reads;
         ft.seg_rounds = best_rounds;
         ft.seg_len = len;
         ft.seg_wfloats = (int)seg_w.size();
@@ -1258,6 +1436,36 @@ int32_t fast_tables_create(pds_stft_plan *plan, const double *window, const int3
         if (rc == PDS_OK) rc = upload(&ft.d_seg_meta, seg_meta.data(), seg_meta.size());
       }
     }
+  }
+  // Row-segment walk (rseg_tables.h; 16-lane geometries).  PDS_STFT_WALK=ell | seg | rseg forces one
+  // of the walks (measurement); by default the one with the fewest 16-byte LDS reads per item runs.
+  if (n2 == 16 && rc == PDS_OK) {
+    RsegTables rs;
+    const int area_floats = 4 * cols * (n2 + 2) * 2;  // WaveGeom::EXCH_F2 * 2
+    if (build_rseg(d.num_filts, row_ptr, col, val, N / 2 + 1, area_floats / 4, 8, rs)) {
+      ft.rs_rounds = rs.rounds;
+      ft.rs_len = rs.seg_len;
+      ft.rs_wfloats = (int)rs.w.size();
+      ft.rs_reads = rs.reads_per_lane();
+      ft.rs_cost = rs.cost;
+      rc = upload(&ft.d_rs_w, rs.w.data(), rs.w.size());
+      if (rc == PDS_OK) rc = upload(&ft.d_rs_meta, rs.meta.data(), rs.meta.size());
+    }
+  }
+  {
+    const char *force = std::getenv("PDS_STFT_WALK");
+    ft.walk = ft.seg_rounds > 0 ? 1 : 0;  // (the segmented walk's own criterion, above)
+    const long other = ft.walk == 1 ? ft.seg_reads : ft.ell_reads;
+    if (ft.rs_rounds > 0 && ft.rs_reads < other) ft.walk = 2;
+    if (force && std::strcmp(force, "ell") == 0) ft.walk = 0;
+    if (force && std::strcmp(force, "seg") == 0) ft.walk = ft.seg_rounds > 0 ? 1 : 0;
+    if (force && std::strcmp(force, "rseg") == 0) ft.walk = ft.rs_rounds > 0 ? 2 : ft.walk;
+    if (std::getenv("PDS_DEBUG_PLAN"))
+      std::fprintf(stderr,
+                   "pds plan N=%d filters=%d: ell slots %d reads %ld | seg rounds %d len %d reads %ld | rseg rounds %d "
+                   "len %d reads %ld cost %ld -> walk %d\n",
+                   N, d.num_filts, ft.ell_slots, ft.ell_reads, ft.seg_rounds, ft.seg_len, ft.seg_reads, ft.rs_rounds,
+                   ft.rs_len, ft.rs_reads, ft.rs_cost, ft.walk);
   }
   if (rc == PDS_OK) rc = upload(&ft.d_ell_w, ell_w.data(), ell_w.size());
   if (rc == PDS_OK) rc = upload(&ft.d_ell_meta, ell_meta.data(), ell_meta.size());
@@ -1273,7 +1481,8 @@ int32_t fast_tables_create(pds_stft_plan *plan, const double *window, const int3
   }
   if (rc == PDS_OK) rc = upload(&ft.d_tw_special, tws.data(), tws.size());
   // matrix-pipe front end (mfma_front.h): the 32 x 16 geometry, tables for the row count of the
-  // instantiation launch_stft_fast_f32 picks.  PDS_STFT_FRONT=valu keeps the in-lane transform.
+  // instantiation launch_stft_fast_f32 picks.  Opt-in (PDS_STFT_FRONT=mfma) while the in-lane
+  // transform measures faster (profiles/r2a_front_ab_counters.txt).
   {
     const char *front = std::getenv("PDS_STFT_FRONT");
     const int rows = (d.frame_length + n2 - 1) / n2;
@@ -1281,7 +1490,7 @@ int32_t fast_tables_create(pds_stft_plan *plan, const double *window, const int3
     for (int b : {20, 25, 28, 30, 32})
       if (!bucket && rows <= b) bucket = b;
     MfmaFrontTables mt;
-    if (rc == PDS_OK && n1 == 32 && n2 == 16 && bucket && !(front && std::strcmp(front, "valu") == 0) &&
+    if (rc == PDS_OK && n1 == 32 && n2 == 16 && bucket && front && std::strcmp(front, "mfma") == 0 &&
         build_mfma_front(n1, bucket, d.frame_length, window, mt)) {
       std::vector<float> image;
       image.reserve(mt.words());
@@ -1316,6 +1525,8 @@ void fast_tables_destroy(pds_stft_plan *plan) {
   (void)hipFree(ft.d_twiddle);
   (void)hipFree(ft.d_tw_special);
   (void)hipFree(ft.d_mf_tab);
+  (void)hipFree(ft.d_rs_w);
+  (void)hipFree(ft.d_rs_meta);
   (void)hipFree(ft.d_seg_w);
   (void)hipFree(ft.d_seg_meta);
   (void)hipFree(ft.d_ell_w);
