@@ -27,6 +27,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip-level parameters)
+VALU_PEAK_TFLOPS = 157.3  # fp32 vector peak, same table (v_fma_f32 at 2 cycles per wave64 instruction)
 # HBM bytes per launch measured with rocprofv3 PMC passes (profiles/run_profile.sh), per workload:
 # FETCH_SIZE x 2 (gfx950 counts a wide coalesced read stream at half its bytes) + WRITE_SIZE
 PMC_TRAFFIC_FILE = os.path.join(ROOT, "profiles", "pmc_traffic.json")
@@ -152,6 +153,46 @@ def cpu_baseline(comp, n, budget_s=12.0):
         "per_core": frames / slowest / cores,
         "reference_python_loop_frames_per_s_per_core": 3650.0,  # BASELINE.md section 2 (authoring container)
     }
+
+
+def parity_spot_check(comp, signal, offsets, lengths, layout, out, picks=3):
+    """Rows of the buffer the timed region wrote, against the oracle on the same samples
+
+    First, middle and last utterance of the batch: their signal slices go to the host, the oracle
+    (float64 restatement of the reference, oracle/stft_oracle.py) computes their features, and the
+    statics columns of `out` must match within the north star's tolerance (1e-5 + 1e-4 |ref|).
+    """
+    import numpy as np
+
+    from oracle import stft_oracle as orc
+
+    p = orc.StftParams(
+        frame_length=comp.frame_length, frame_shift=comp.frame_shift, dft_size=comp.dft_size,
+        window=np.asarray(comp._window), starts=list(comp._filt_start_idxs),
+        taps=[np.asarray(t) for t in comp._truncated_filts], is_real=comp.bank.is_real,
+        centered=comp.frame_style == "centered", kaldi_shift=comp.kaldi_shift,
+        include_energy=comp.includes_energy, use_power=bool(comp._power), use_log=bool(comp._log),
+    )
+    B, C = len(lengths), comp.num_coeffs
+    worst_abs = worst_tol = 0.0
+    rows = 0
+    utts = sorted({0, B // 2, B - 1})[:picks]
+    for b in utts:
+        x = signal[int(offsets[b]) : int(offsets[b] + lengths[b])].cpu().numpy()
+        want = orc.compute_full(x, p)
+        r0 = int(layout.row_offsets[b])
+        got = out[r0 : r0 + want.shape[0], :C].cpu().numpy().astype(np.float64)
+        if got.shape != want.shape or not want.size:
+            return {"pass": False, "error": f"utterance {b}: shape {got.shape} against {want.shape}"}
+        err = np.abs(got - want)
+        if np.isnan(err).any():
+            return {"pass": False, "error": f"utterance {b}: NaN"}
+        worst_abs = max(worst_abs, float(err.max()))
+        worst_tol = max(worst_tol, float((err / (1e-5 + 1e-4 * np.abs(want))).max()))
+        rows += want.shape[0]
+    return {"pass": worst_tol <= 1.0, "utterances": utts, "rows": rows, "coeffs": C, "max_abs_err": worst_abs,
+            "max_err_over_tolerance": worst_tol, "tolerance": "1e-5 + 1e-4 |ref|",
+            "against": "oracle/stft_oracle.compute_full (float64) on the timed buffer's own input"}
 
 
 def _stdout_to_stderr():
@@ -303,7 +344,10 @@ def main():
     # clocks take depends on what the box did before: after the CPU-baseline leg the ramp takes
     # ~150 ms, not ~40), at most 2 s.
     preroll = 0
+    cold_ms = None  # mean step time of the first 20 launches (idle clocks), next to the steady state
     if args.preroll_ms > 0:
+        step()  # (first launch: plan tables, kernel attributes, module load)
+        torch.cuda.synchronize(dev)
         t_start = time.perf_counter()
         best, settled = float("inf"), 0
         while True:
@@ -314,6 +358,8 @@ def main():
             now = time.perf_counter()
             preroll += 20
             block = now - t_block
+            if cold_ms is None:
+                cold_ms = 1e3 * block / 20
             settled = 0 if block < 0.995 * best else settled + 1  # (a ramp gains 1-3 % per block)
             best = min(best, block)
             if (now - t_start >= 1e-3 * args.preroll_ms and settled >= 8) or now - t_start > 2.0:
@@ -343,6 +389,9 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     finite = bool(torch.isfinite(out).all().item())
+    spot = None
+    if rank == 0 and not is_si:
+        spot = parity_spot_check(comp, signal, offsets, lengths, layout, out)
 
     def timed_gather():
         gathered = torch.empty((world * frames, out_cols), dtype=torch.float32, device=dev)
@@ -380,14 +429,32 @@ def main():
         achieved = frames * bytes_per_frame / k_avg_s / 1e9
         value = world * frames * args.steps / elapsed
         traffic = traffic_bytes = None
+        rec = None
         try:
             with open(PMC_TRAFFIC_FILE) as fh:
                 rec = json.load(fh).get(args.workload)
             if rec and rec["frames_per_launch"] == frames and not args.generic and not args.ragged:
                 traffic_bytes = rec["hbm_bytes_per_launch"]
                 traffic = traffic_bytes / k_avg_s / 1e9
+            else:
+                rec = None
         except (OSError, ValueError, KeyError):
-            pass
+            rec = None
+        # the ceilings the kernel meets before the HBM one.  Algorithmic flops
+        # per frame: rFFT-N (~2.5 N log2 N) + window + |X|^2 + 2 flops per filter tap.
+        secondary = None
+        if not is_si:
+            N = comp.dft_size
+            taps = int(sum(len(t) for t in comp._truncated_filts))
+            flop_per_frame = 2.5 * N * np.log2(N) + comp.frame_length + 3 * (N // 2 + 1) + 2 * taps
+            secondary = {
+                "fp32_valu": {"achieved_tflops": frames / k_avg_s * flop_per_frame / 1e12, "peak_tflops": VALU_PEAK_TFLOPS,
+                              "frac": frames / k_avg_s * flop_per_frame / 1e12 / VALU_PEAK_TFLOPS,
+                              "algorithmic_flop_per_frame": float(flop_per_frame)},
+                "lds": ({"busy_frac_pmc": rec.get("lds_busy_frac"), "bank_conflict_share_pmc": rec.get("lds_bank_conflict_share"),
+                         "valu_instr_per_frame_pmc": rec.get("valu_instr_per_frame"), "source": rec.get("sq_source")}
+                        if rec else None),
+            }
         line = {
             "metric": "frames/s (whole node) + HBM-roofline %, 40-mel fbank 16kHz 25/10ms"
             if args.workload == DEFAULT_WORKLOAD else f"frames/s ({args.workload})",
@@ -420,8 +487,11 @@ def main():
                 "kernel_ms_avg": 1e3 * k_avg_s, "kernel_ms_min": float(np.min(kernel_ms)),
                 "algorithmic_bytes_per_frame": bytes_per_frame,
                 "frames_per_s_per_gpu_kernel_only": frames / k_avg_s,
+                "secondary": secondary,
             },
+            "cold_ms_per_step": cold_ms,
             "outputs_finite": finite,
+            "parity_spot_check": spot,
         }
         if is_si:
             # compute bound: fused multiply-adds of the FIR bank per launch against the vector peak

@@ -61,6 +61,14 @@ def test_bench_prints_one_json_line_with_the_contract_fields():
     assert line["dtype"] == "f32" and line["data"] == "synthetic" and "workload" in line["config"]
     assert line["roofline"]["bound"] == "hbm" and line["roofline"]["peak"] == 8000.0
     assert 0 < line["roofline"]["frac"] < 1 and line["value"] > 0 and line["outputs_finite"] is True
+    # self-proving line: rows of the timed buffer against the oracle, the secondary ceilings, the cold step time
+    spot = line["parity_spot_check"]
+    assert spot["pass"] is True and spot["rows"] > 0 and spot["max_err_over_tolerance"] <= 1.0
+    sec = line["roofline"]["secondary"]
+    assert sec["fp32_valu"]["peak_tflops"] == 157.3 and 0 < sec["fp32_valu"]["frac"] < 1
+    assert 10e3 < sec["fp32_valu"]["algorithmic_flop_per_frame"] < 20e3  # ~14 kflop per frame
+    assert "lds" in sec
+    assert line["cold_ms_per_step"] > 0
 
 
 @pytest.mark.gpu
