@@ -273,6 +273,50 @@ int32_t pds_si_batch_f64(const pds_si_plan *plan, const double *d_signal, const 
                          const int64_t *d_row_off, int32_t B, int64_t max_frames, int64_t start,
                          double *d_out, int64_t out_stride, void *stream);
 
+/* ---------------------------------------------------------------------------------
+ * Multi-GPU: gather of feature rows over RCCL (xGMI inside a node).
+ *
+ * The reference has no counterpart: its only parallelism is DataLoader worker processes
+ * (command_line.py:594).  The path shards by utterance with no data dependence (SURVEY.md
+ * section 8 e); what a caller that wants every feature matrix in one place needs is ONE
+ * all-gather of the rows each GPU produced.  RCCL (librccl.so.1) is loaded on first use:
+ * the other entry points of this library do not need it.
+ *
+ * Two ways to make communicators:
+ *   - one process per GPU: rank 0 calls pds_comm_unique_id and hands the 128 bytes to the
+ *     other ranks (any channel: a file, MPI, torch.distributed's store); every rank then calls
+ *     pds_comm_init_rank with its own current device;
+ *   - one process driving several GPUs: pds_comm_init_all (ncclCommInitAll), one handle per
+ *     device; calls on several handles from one thread go between pds_comm_group_start / _end.
+ * --------------------------------------------------------------------------------- */
+typedef struct pds_comm pds_comm;
+
+#define PDS_COMM_ID_BYTES 128
+int32_t pds_comm_unique_id(void *id128);
+int32_t pds_comm_init_rank(const void *id128, int32_t world, int32_t rank, pds_comm **comm_out);
+/* comms_out: array of ndev handles; devices: ndev HIP device ordinals (NULL = 0 .. ndev - 1) */
+int32_t pds_comm_init_all(int32_t ndev, const int32_t *devices, pds_comm **comms_out);
+int32_t pds_comm_world(const pds_comm *comm);
+int32_t pds_comm_rank(const pds_comm *comm);
+void pds_comm_destroy(pds_comm *comm);
+int32_t pds_comm_group_start(void);
+int32_t pds_comm_group_end(void);
+
+/*
+ * All-gather of rows: rank r contributes rows_per_rank[r] rows of row_bytes bytes from its
+ * d_local; every rank receives all rows, in rank order (= utterance order for contiguous
+ * utterance blocks), in its d_out (sum(rows_per_rank) * row_bytes bytes; d_local may be the
+ * rank's own slice of d_out).  rows_per_rank: HOST array of `world` entries, the same on every
+ * rank (frame counts are a pure function of the utterance lengths, compute.py:596).  Equal
+ * shards are one ncclAllGather; ragged shards one group of ncclBroadcast, one per rank.
+ * Enqueued on `stream`; nothing here synchronises.
+ */
+int32_t pds_gather_rows(pds_comm *comm, const void *d_local, const int64_t *rows_per_rank,
+                        int64_t row_bytes, void *d_out, void *stream);
+/* sum over ranks of a small table, in place (corpus-level CMVN statistics over a sharded
+ * corpus: float64[2][C + 1], post.py:193-212) */
+int32_t pds_allreduce_sum_f64(pds_comm *comm, double *d_table, int64_t count, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -130,6 +130,17 @@ SIGNATURES = {
     "pds_cmvn_apply_f64": (c_int32, [c_void_p, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
     "pds_cmvn_rows_f32": (c_int32, _CMVN_ROWS_ARGS),
     "pds_cmvn_rows_f32out": (c_int32, _CMVN_ROWS_ARGS),
+    # multi-GPU gather over RCCL
+    "pds_comm_unique_id": (c_int32, [c_void_p]),
+    "pds_comm_init_rank": (c_int32, [c_void_p, c_int32, c_int32, POINTER(c_void_p)]),
+    "pds_comm_init_all": (c_int32, [c_int32, c_void_p, POINTER(c_void_p)]),
+    "pds_comm_world": (c_int32, [c_void_p]),
+    "pds_comm_rank": (c_int32, [c_void_p]),
+    "pds_comm_destroy": (None, [c_void_p]),
+    "pds_comm_group_start": (c_int32, []),
+    "pds_comm_group_end": (c_int32, []),
+    "pds_gather_rows": (c_int32, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
+    "pds_allreduce_sum_f64": (c_int32, [c_void_p, c_void_p, c_int64, c_void_p]),
 }
 
 _lib = None

@@ -69,6 +69,22 @@ WORKER = textwrap.dedent(
         assert a.shape == b.shape and np.array_equal(a, b)
     lo, own = compute_full_sharded(FakeComputer(), signals, gather=False)
     assert lo == shard_bounds(len(signals), world, rank)[0]
+    # fewer signals than ranks, float64: the rank with the empty shard takes the dtype from the others
+    one = [rng.standard_normal(120)]
+    feats = compute_full_sharded(FakeComputer(), one)
+    assert len(feats) == 1 and feats[0].dtype == np.float64
+    assert np.array_equal(feats[0], FakeComputer().compute_full_batch(one)[0])
+    assert compute_full_sharded(FakeComputer(), []) == []
+    # only the rank's own block is read: everything else may be a placeholder
+    lo, hi = shard_bounds(len(signals), world, rank)
+    holes = [s if lo <= i < hi else None for i, s in enumerate(signals)]
+    feats = compute_full_sharded(FakeComputer(), holes)
+    for a, b in zip(feats, want):
+        assert a.shape == b.shape and np.array_equal(a, b)
+    # ragged gather with counts known in advance
+    n = rank + 2
+    out = gather_rows(torch.full((n, 3), float(rank)), counts=[r + 2 for r in range(world)])
+    assert out.shape == (sum(r + 2 for r in range(world)), 3) and float(out[-1, 0]) == world - 1
     # global CMVN statistics: the sum over ranks of what each accumulated; a rank with an empty
     # shard (no statistics yet) contributes zeros
     from pydrobert_speech_amd.dist import all_reduce_stats

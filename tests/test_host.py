@@ -346,3 +346,16 @@ def test_parity_helper_sees_nan():
         assert_features_close([0.5, 1.0], [np.nan, 1.0], 1e-4, 1e-5)
     with pytest.raises(AssertionError):
         assert_features_close([0.5, 1.1], [0.5, 1.0], 1e-4, 1e-5)
+
+
+def test_comm_entry_points_validate_arguments_without_a_device():
+    # argument checks of the gather exports come before RCCL is even loaded
+    lib = _native.lib()
+    assert lib.pds_comm_world(None) == 0 and lib.pds_comm_rank(None) == -1
+    lib.pds_comm_destroy(None)
+    assert lib.pds_comm_unique_id(None) == -1 and b"null" in lib.pds_last_error()
+    handle = ctypes.c_void_p()
+    ident = ctypes.create_string_buffer(128)
+    assert lib.pds_comm_init_rank(ident, 2, 2, ctypes.byref(handle)) == -1 and b"rank" in lib.pds_last_error()
+    assert lib.pds_gather_rows(None, None, None, 4, None, None) == -1
+    assert lib.pds_allreduce_sum_f64(None, None, 4, None) == -1

@@ -11,7 +11,7 @@ flags="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wall -Wno-unused-result -ffp-
 [ "$src" = stft_fast.hip ] && flags="$flags -fno-signed-zeros"
 /opt/rocm/bin/hipcc $flags "$@" -c $src -o /tmp/variant_$name.o
 objs=""
-for o in capi stft_generic stft_fast post pre si si_fft; do
+for o in capi stft_generic stft_fast post pre si si_fft comm; do
   if [ "$o.hip" = "$src" ]; then objs="$objs /tmp/variant_$name.o"; else objs="$objs $o.o"; fi
 done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $objs -o /root/repo/variants/lib_$name.so
