@@ -227,6 +227,9 @@ def main():
     ap.add_argument("--ragged", action="store_true",
                     help="utterance lengths uniform in [1 s, 15 s] at the workload's rate (seed 99; "
                          "SURVEY.md section 8(d)) instead of the workload's fixed length")
+    ap.add_argument("--dtype", default="f32", choices=["f32", "f64in"],
+                    help="f64in: float64 samples in HBM, rounded to float32 by the fused kernel as it loads the "
+                         "frames (pds_stft_batch_f64in), float32 features -- the reference drivers' dtype flow")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true")
     ap.add_argument("--generic", action="store_true",
@@ -301,6 +304,11 @@ def main():
         lengths = np.full(B, n, dtype=np.int64)
     offsets = np.concatenate([[0], np.cumsum(lengths)[:-1]]).astype(np.int64)
     signal = torch.randn(int(lengths.sum()), generator=g, device=dev, dtype=torch.float32).mul_(3000.0)
+    if args.dtype == "f64in":
+        if is_si:
+            raise SystemExit("--dtype f64in: STFT workloads only")
+        signal = signal.double()
+        ps.config.FLOAT64_ARITHMETIC = "float32"
     if is_si:
         layout = None
         frames = int(sum(comp.num_frames(int(v)) for v in lengths))
@@ -422,7 +430,7 @@ def main():
 
     if rank == 0:
         # every sample read once, every output coefficient written once
-        bytes_per_frame = 4 * comp.frame_shift + 4 * out_cols
+        bytes_per_frame = (8 if args.dtype == "f64in" else 4) * comp.frame_shift + 4 * out_cols
         if cmvn is not None:
             bytes_per_frame += 4 * C + 8 * C  # second read of the features + float64 result
         k_avg_s = 1e-3 * float(np.mean(kernel_ms))
@@ -433,7 +441,7 @@ def main():
         try:
             with open(PMC_TRAFFIC_FILE) as fh:
                 rec = json.load(fh).get(args.workload)
-            if rec and rec["frames_per_launch"] == frames and not args.generic and not args.ragged:
+            if rec and rec["frames_per_launch"] == frames and not args.generic and not args.ragged and args.dtype == "f32":
                 traffic_bytes = rec["hbm_bytes_per_launch"]
                 traffic = traffic_bytes / k_avg_s / 1e9
             else:
@@ -471,7 +479,8 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {
-                "workload": args.workload + ("+ragged_1to15s" if args.ragged else ""), "utterances_per_gpu": B,
+                "workload": args.workload + ("+ragged_1to15s" if args.ragged else "")
+                            + ("+float64_samples" if args.dtype == "f64in" else ""), "utterances_per_gpu": B,
                 "samples_per_utterance": int(lengths.mean()),
                 "frames_per_gpu_per_step": frames, "num_coeffs": comp.num_coeffs, "post": post,
                 "frame_length": comp.frame_length, "frame_shift": comp.frame_shift,

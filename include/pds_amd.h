@@ -120,6 +120,21 @@ int32_t pds_stft_batch_f64(const pds_stft_plan *plan, const double *d_signal,
                            const int64_t *d_nframes, const int64_t *d_row_off, int32_t B,
                            int64_t max_frames, int32_t pad_left, double preemph, double *d_out,
                            int64_t out_stride, void *stream);
+/* float64 signals, float32 ARITHMETIC (the fused kernel): every sample is rounded to float32 as its
+ * frame is loaded (a fused pre-emphasis is applied before that, in float64, so the samples framed are
+ * bit-identical to the reference's own pass, pre.py:140-149), features are float32 (out_is_f64 = 0)
+ * or widened to float64 at the store (out_is_f64 = 1: compute_full's "output dtype = input dtype",
+ * compute.py:601; not together with preemph != 0).  This is the dtype flow of the reference's drivers
+ * -- float64 audio in, float32 features stored (command_line.py:107-108, 345-350) -- without a
+ * conversion pass over the signal.  Served for plans of the common power-of-two transform sizes
+ * (256, 512, 1024, 2048) whose filter tables are LDS-resident: pds_stft_plan_has_f64in(); results
+ * are within the float32 tolerance (1e-5 + 1e-4 |ref|), not the 1e-9 of pds_stft_batch_f64. */
+int32_t pds_stft_plan_has_f64in(const pds_stft_plan *plan);
+int32_t pds_stft_batch_f64in(const pds_stft_plan *plan, const double *d_signal,
+                             const int64_t *d_offsets, const int64_t *d_lengths,
+                             const int64_t *d_nframes, const int64_t *d_row_off, int32_t B,
+                             int64_t max_frames, int32_t pad_left, double preemph, void *d_out,
+                             int32_t out_is_f64, int64_t out_stride, void *stream);
 /* float32 input through the generic kernels regardless of N: radix-2 FFT in LDS for powers of two,
  * direct DFT otherwise (cross-check of the fused kernel; also what sizes without a fused geometry use) */
 int32_t pds_stft_batch_f32_generic(const pds_stft_plan *plan, const float *d_signal,

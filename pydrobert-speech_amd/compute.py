@@ -196,6 +196,7 @@ class _NativePlan:
         _native.check(rc, "pds_stft_plan_create")
         self.handle = handle
         self.kernel_kind = lib.pds_stft_plan_kernel_kind(handle)
+        self.has_f64in = bool(lib.pds_stft_plan_has_f64in(handle))
 
     def __del__(self):
         handle, self.handle = getattr(self, "handle", None), None
@@ -417,14 +418,35 @@ class ShortTimeFourierTransformFrameComputer(LinearFilterBankFrameComputer):
         plan = self._native_plan(signal.device)
         if layout.extent > signal.numel():
             raise ValueError("an utterance lies outside the signal buffer")
-        if signal.dtype == torch.float64 and config.FLOAT64_ARITHMETIC == "float32" and not generic:
-            # opt-in: float32 arithmetic for float64 data (config.FLOAT64_ARITHMETIC)
+        f64in = signal.dtype == torch.float64 and config.FLOAT64_ARITHMETIC == "float32" and not generic
+        if f64in and not plan.has_f64in:
+            # opt-in float32 arithmetic for float64 data at a transform size without a fused
+            # float64-input kernel: round the samples first
             feats = self.launch(signal.to(torch.float32), layout, pad_left=pad_left, preemphasis=preemphasis)
             if out is None:
                 return feats.to(torch.float64)
             out[: feats.shape[0], : feats.shape[1]] = feats
             return out
-        if signal.dtype == torch.float32:
+        if f64in and preemphasis and (out is None or out.dtype == torch.float64):
+            # (float64 features with fused pre-emphasis: float32 features from the same kernel, widened)
+            feats = self.launch(signal, layout, pad_left=pad_left, preemphasis=preemphasis,
+                                out=torch.empty((layout.total_rows, self.num_coeffs), dtype=torch.float32,
+                                                device=signal.device))
+            if out is None:
+                return feats.to(torch.float64)
+            out[: feats.shape[0], : feats.shape[1]] = feats
+            return out
+        out_dtype = signal.dtype
+        if f64in:
+            # the fused kernel rounds the samples as it loads them and stores float32 or float64 features
+            out_dtype = torch.float64 if out is None else out.dtype
+            if out_dtype not in (torch.float32, torch.float64):
+                raise ValueError("out has the wrong dtype, shape or strides")
+            is64 = int(out_dtype == torch.float64)
+
+            def fn(*args):
+                return lib.pds_stft_batch_f64in(*args[:11], is64, *args[11:])
+        elif signal.dtype == torch.float32:
             fn = lib.pds_stft_batch_f32_generic if generic else lib.pds_stft_batch_f32
         elif signal.dtype == torch.float64:
             fn = lib.pds_stft_batch_f64
@@ -432,9 +454,9 @@ class ShortTimeFourierTransformFrameComputer(LinearFilterBankFrameComputer):
             raise TypeError("signal must be float32 or float64")
         total = layout.total_rows
         if out is None:
-            out = torch.empty((total, self.num_coeffs), dtype=signal.dtype, device=signal.device)
+            out = torch.empty((total, self.num_coeffs), dtype=out_dtype, device=signal.device)
         elif (
-            out.dtype != signal.dtype
+            out.dtype != out_dtype
             or out.dim() != 2
             or out.shape[0] < total
             or out.shape[1] < self.num_coeffs

@@ -18,9 +18,10 @@ LOG_FLOOR_VALUE: float = 1e-5
 
 #: How float64 signals are computed by the STFT computer.  ``"float64"`` (default): float64
 #: arithmetic throughout, the reference's own internal precision, on the generic kernels
-#: (results within 1e-9 of the reference; ~370 M frames/s at power-of-two transform sizes).  ``"float32"``: the samples are
-#: rounded to float32 on the device, take the fused float32 kernel (results within the
-#: float32 tolerance 1e-5 + 1e-4 |ref|; ~3 G frames/s) and the features are widened back,
-#: so the returned dtype still follows the input as in the reference (compute.py:601).
-#: Read at every launch.
+#: (results within 1e-9 of the reference; ~370 M frames/s at power-of-two transform sizes).  ``"float32"``: the fused
+#: kernel rounds every sample to float32 as it loads the frame and widens the features at the
+#: store (results within the float32 tolerance 1e-5 + 1e-4 |ref|; no conversion pass over the
+#: signal at transform sizes 256 ... 2048), so the returned dtype still follows the input as in
+#: the reference (compute.py:601); an `out` tensor of float32 receives float32 features, the dtype
+#: flow of the reference's drivers (command_line.py:107-108, 345-350).  Read at every launch.
 FLOAT64_ARITHMETIC: str = "float64"

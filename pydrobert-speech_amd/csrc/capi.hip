@@ -183,4 +183,24 @@ int32_t pds_stft_batch_f64(const pds_stft_plan *plan, const double *d_signal,
   PDS_BATCH_BODY(pds::launch_stft_generic_f64)
 }
 
+int32_t pds_stft_plan_has_f64in(const pds_stft_plan *plan) { return plan && pds::fast_has_f64in(plan) ? 1 : 0; }
+
+int32_t pds_stft_batch_f64in(const pds_stft_plan *plan, const double *d_signal, const int64_t *d_offsets,
+                             const int64_t *d_lengths, const int64_t *d_nframes, const int64_t *d_row_off,
+                             int32_t B, int64_t max_frames, int32_t pad_left, double preemph, void *d_out,
+                             int32_t out_is_f64, int64_t out_stride, void *stream) {
+  int32_t rc = check_batch(plan, d_signal, d_offsets, d_lengths, d_nframes, d_row_off, B, max_frames, pad_left,
+                           d_out, out_stride);
+  if (rc == 1) return PDS_OK;
+  if (rc != PDS_OK) return rc;
+  if (!pds::fast_has_f64in(plan)) return invalid("stft_batch_f64in: the plan has no fused float64-input kernel");
+  rc = pds::check_plan_device(plan->device, "stft_batch");
+  if (rc != PDS_OK) return rc;
+  pds::BatchArgs a{d_signal,   d_offsets, d_lengths,  d_nframes, d_row_off, B, max_frames,
+                   pad_left < 0 ? plan->d.pad_left : pad_left, preemph, d_out, out_stride, (hipStream_t)stream};
+  a.in_f64 = true;
+  a.out_f64 = out_is_f64 != 0;
+  return pds::launch_stft_fast_f32(plan, a);
+}
+
 }  // extern "C"

@@ -112,6 +112,9 @@ struct BatchArgs {
   void *d_out;
   int64_t out_stride;
   hipStream_t stream;
+  // fused kernel only: float64 samples rounded at the frame load / float64 features widened at the
+  // store (float32 arithmetic either way); pds_stft_batch_f64in
+  bool in_f64 = false, out_f64 = false;
 };
 
 // stft_generic.hip
@@ -122,6 +125,7 @@ int32_t fast_tables_create(pds_stft_plan *plan, const double *window, const int3
                            const int32_t *col, const double *val);
 void fast_tables_destroy(pds_stft_plan *plan);
 int32_t launch_stft_fast_f32(const pds_stft_plan *plan, const BatchArgs &a);
+bool fast_has_f64in(const pds_stft_plan *plan);
 
 // Runs `body` (plan construction: host allocations) so that no C++ exception crosses the C ABI.
 template <typename F>

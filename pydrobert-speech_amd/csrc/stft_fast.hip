@@ -33,6 +33,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <type_traits>
 #include <vector>
 
 #include "fft_inlane.h"
@@ -101,9 +102,9 @@ extern "C" __attribute__((visibility("default"))) void pds_debug_set_stamp_buffe
 __device__ __forceinline__ void keep_alive(float v) { asm volatile("" ::"v"(v)); }
 
 struct FastParams {
-  const float *sig;
+  const void *sig;  // TIN samples
   const int64_t *offsets, *lengths, *nframes, *row_off;
-  float *out;
+  void *out;  // TOUT features
   int64_t out_stride;
   const float *win_lane;    // [N2][N1]   window[N2*n1 + n2], zero beyond L
   const float2 *tw_lane;    // [N2][N1/2] W_N^(n2*k1), pre-scaled (see rdft_scaled)
@@ -119,6 +120,7 @@ struct FastParams {
   int seg_rounds, seg_len, num_filts;
   int L, S, pad_left, include_energy, use_power, use_log;
   float log_floor, inv_L, preemph;
+  double preemph_d;  // the coefficient at full precision (float64 samples)
   int chunks_per_utt, num_utts;
   int waves;  // wavefronts per workgroup of this launch (<= MAXWAVES)
   const float *mf_tab;  // matrix-pipe front end (MF instantiations): image of MfmaFrontTables
@@ -225,9 +227,16 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 //
 // RSG: the filter phase is the row-segment walk of rseg_tables.h (power spectra bin-major in LDS,
 // a lane = one segment of one filter for all four frames; 16-lane geometries, tables in LDS)
+//
+// TIN / TOUT: sample and feature types in memory.  The arithmetic is float32 whatever they are:
+// float64 samples are rounded as the frame is loaded (pre-emphasis, if fused, before the rounding, in
+// float64 like the reference's own pass), float64 features are widened at the store -- the dtype flow
+// of the reference's drivers (float64 audio in, compute.py:601 output dtype = input dtype) without
+// separate conversion passes over the signal and the features.
 template <int N1, int N2, int NROWS, int MAXWAVES, int MINW, bool ELL_LDS, bool PRE, bool SEG = false, int MF = 0,
-          bool RSG = false>
+          bool RSG = false, typename TIN = float, typename TOUT = float>
 __global__ __launch_bounds__(MAXWAVES * 64, MINW) void stft_wave_kernel(const FastParams p) {
+  static_assert(MF == 0 || std::is_same<TIN, float>::value, "matrix-pipe front end: float32 samples");
   using G = WaveGeom<N1, N2, NROWS>;
   constexpr int N = G::N, COLS = G::COLS, NREG = G::NREG, RS = G::RS, NB = G::NB, PSTR = G::PSTR;
   constexpr int MSLOTS = 2 * MF + 1;  // per-lane sample slots of a frame (MF)
@@ -353,7 +362,7 @@ __global__ __launch_bounds__(MAXWAVES * 64, MINW) void stft_wave_kernel(const Fa
     PDS_STAMP(7, 0);  // item bookkeeping (and whatever the previous item left undrained)
     if constexpr (PDS_STAMPS) ++st_acc[6];
     PDS_PHASE(0);
-    const float *x = p.sig + sig_off;
+    const TIN *x = static_cast<const TIN *>(p.sig) + sig_off;
     const int start0 = tb * S - p.pad_left;
     bool valid = true;
     float energy = 0.0f;
@@ -387,7 +396,7 @@ __global__ __launch_bounds__(MAXWAVES * 64, MINW) void stft_wave_kernel(const Fa
 #pragma unroll
         for (int fg = 0; fg < 4; ++fg) {
           // scalar frame base + the lane's 32-bit byte offset: no 64-bit vector arithmetic
-          const char *xg = reinterpret_cast<const char *>(x + fstart[fg]);
+          const char *xg = reinterpret_cast<const char *>(reinterpret_cast<const float *>(x) + fstart[fg]);
 #pragma unroll
           for (int sl = 0; sl < MSLOTS; ++sl) {
             float v = (PDS_ABLATE & 1) ? (float)(lane + sl) : *reinterpret_cast<const float *>(xg + moff[sl]);
@@ -409,8 +418,8 @@ __global__ __launch_bounds__(MAXWAVES * 64, MINW) void stft_wave_kernel(const Fa
             } else {
               i = (int)reflect_index((int64_t)i, (int64_t)n);
             }
-            float v = x[i];
-            if (PRE && i > 0) v = preemph_sample(v, x[i - 1], p.preemph);
+            float v = (float)x[i];
+            if (PRE && i > 0) v = preemph_sample(v, (float)x[i - 1], p.preemph);
             tmp[(fg * MSLOTS + sl) * 64 + lane] = v;
           }
         }
@@ -537,16 +546,27 @@ __global__ __launch_bounds__(MAXWAVES * 64, MINW) void stft_wave_kernel(const Fa
       if (wmode == 0) {
         // Lanes past the frame's end in the last row read samples of the next frame; the
         // window (exactly 0 there, applied with the 0 * x = 0 multiply) removes them.
-        const float *xp = x + (start + r);
+        const TIN *xp = x + (start + r);
+        if constexpr (!std::is_same<TIN, float>::value) {
+          // float64 samples: 8-byte loads, pre-emphasis in float64 (bit-identical to the reference's
+          // own pass, pre.py:140-149), one rounding to float32
 #pragma unroll
-        for (int n1 = 0; n1 < NROWS; ++n1) a[n1] = (PDS_ABLATE & 1) ? (float)(lane + n1) : xp[n1 * N2];
-        if constexpr (PRE) {
+          for (int n1 = 0; n1 < NROWS; ++n1) {
+            TIN v = xp[n1 * N2];
+            if constexpr (PRE) v = preemph_sample(v, xp[n1 * N2 - 1], (TIN)p.preemph_d);
+            a[n1] = (float)v;
+          }
+        } else {
+#pragma unroll
+        for (int n1 = 0; n1 < NROWS; ++n1) a[n1] = (PDS_ABLATE & 1) ? (float)(lane + n1) : (float)xp[n1 * N2];
+        }
+        if constexpr (PRE && std::is_same<TIN, float>::value) {
           // predecessor of lane r's sample: lane r - 1 of the same row, or (r = 0) the last lane
           // of the previous row.  With 16 lanes per frame a lane group is one DPP row and
           // row_ror:1 delivers both; other group sizes load the predecessor.
           if constexpr (N2 == 16) {
             float carry = 0.0f;
-            if (r == 0) carry = xp[-1];
+            if (r == 0) carry = (float)xp[-1];
 #pragma unroll
             for (int n1 = 0; n1 < NROWS; ++n1) {
               const float rot = __int_as_float(__builtin_amdgcn_update_dpp(
@@ -557,7 +577,7 @@ __global__ __launch_bounds__(MAXWAVES * 64, MINW) void stft_wave_kernel(const Fa
             }
           } else {
 #pragma unroll
-            for (int n1 = 0; n1 < NROWS; ++n1) a[n1] = preemph_sample(a[n1], xp[n1 * N2 - 1], p.preemph);
+            for (int n1 = 0; n1 < NROWS; ++n1) a[n1] = preemph_sample(a[n1], (float)xp[n1 * N2 - 1], p.preemph);
           }
         }
       } else {
@@ -573,8 +593,14 @@ __global__ __launch_bounds__(MAXWAVES * 64, MINW) void stft_wave_kernel(const Fa
             } else {
               i = (int)reflect_index((int64_t)i, (int64_t)n);
             }
-            v = x[i];
-            if (PRE && i > 0) v = preemph_sample(v, x[i - 1], p.preemph);
+            if constexpr (std::is_same<TIN, float>::value) {
+              v = (float)x[i];
+              if (PRE && i > 0) v = preemph_sample(v, (float)x[i - 1], p.preemph);
+            } else {
+              TIN w = x[i];
+              if (PRE && i > 0) w = preemph_sample(w, x[i - 1], (TIN)p.preemph_d);
+              v = (float)w;
+            }
           }
           tmp[n1 * 64 + lane] = v;
         }
@@ -797,7 +823,7 @@ __global__ __launch_bounds__(MAXWAVES * 64, MINW) void stft_wave_kernel(const Fa
     }
     // ---- filter bank: lane (g, r) integrates one filter per slot
     // scalar row base + a 32-bit lane offset: no 64-bit vector arithmetic per store
-    float *obase = p.out + (out_row + tb) * p.out_stride;
+    TOUT *obase = static_cast<TOUT *>(p.out) + (out_row + tb) * p.out_stride;
     const unsigned lane_off = (unsigned)(g * (int)p.out_stride + col0);
     if (p.include_energy) {
       // sum over the frame's lanes with DPP butterflies (lanes 1^, 2^, 7-, 15- within the row);
@@ -814,7 +840,7 @@ __global__ __launch_bounds__(MAXWAVES * 64, MINW) void stft_wave_kernel(const Fa
       float e = energy * p.inv_L;
       if (!use_power) e = __builtin_amdgcn_sqrtf(e);
       if (p.use_log) e = fast_log(p.log_floor > e ? p.log_floor : e);
-      if (valid && r == 0) obase[lane_off - col0] = e;
+      if (valid && r == 0) obase[lane_off - col0] = (TOUT)e;
     }
     PDS_STAMP(4, 0);  // P stores, energy
     PDS_PHASE(3);
@@ -874,9 +900,9 @@ __global__ __launch_bounds__(MAXWAVES * 64, MINW) void stft_wave_kernel(const Fa
         keep_alive(acc);
       } else {
         // filter index f = (meta >> 16) - 1; lanes without a filter in this slot have meta < 2^16
-        const unsigned byte_off = (lane_off + (unsigned)(meta >> 16) - 1u) * 4u;
+        const unsigned byte_off = (lane_off + (unsigned)(meta >> 16) - 1u) * (unsigned)sizeof(TOUT);
         if (valid && meta >= 0x10000)
-          *reinterpret_cast<float *>(reinterpret_cast<char *>(obase) + byte_off) = acc;
+          *reinterpret_cast<TOUT *>(reinterpret_cast<char *>(obase) + byte_off) = (TOUT)acc;
       }
     };
     if constexpr (RSG) {
@@ -939,13 +965,13 @@ __global__ __launch_bounds__(MAXWAVES * 64, MINW) void stft_wave_kernel(const Fa
         a3 = fmaf(shl(a3, inl::Int<0x102>{}), m2, a3);
         const int f = (meta >> 16) - 1;  // the filter, on the first lane of its run; -1 elsewhere
         const float vals[4] = {a0, a1, a2, a3};
-        float *dst = obase + col0 + (f < 0 ? 0 : f);
+        TOUT *dst = obase + col0 + (f < 0 ? 0 : f);
 #pragma unroll
         for (int gg = 0; gg < 4; ++gg) {
           float v = vals[gg];
           // max(val, floor) as Python evaluates it: a NaN stays a NaN (compute.py:459)
           if (p.use_log) v = fast_log(p.log_floor > v ? p.log_floor : v);
-          if (f >= 0 && gg < frames_here) dst[(int64_t)gg * p.out_stride] = v;
+          if (f >= 0 && gg < frames_here) dst[(int64_t)gg * p.out_stride] = (TOUT)v;
         }
       }
       PDS_STAMP(5, 0);  // filter walk
@@ -1016,7 +1042,7 @@ __global__ __launch_bounds__(MAXWAVES * 64, MINW) void stft_wave_kernel(const Fa
             float v = vals[gg];
             // max(val, floor) as Python evaluates it: a NaN stays a NaN (compute.py:459)
             if (p.use_log) v = fast_log(p.log_floor > v ? p.log_floor : v);
-            if (gg < frames_here) obase[(int64_t)gg * p.out_stride + col0 + f] = v;
+            if (gg < frames_here) obase[(int64_t)gg * p.out_stride + col0 + f] = (TOUT)v;
           }
         }
         PDS_STAMP(5, 0);  // filter walk
@@ -1045,18 +1071,23 @@ __global__ __launch_bounds__(MAXWAVES * 64, MINW) void stft_wave_kernel(const Fa
 
 // ----------------------------------------------------------------------- host side ---
 
+// transform sizes with float64-input instantiations of the fused kernel
+constexpr bool fast_f64in_kind(int n) { return n == 256 || n == 512 || n == 1024 || n == 2048; }
+
+bool fast_has_f64in(const pds_stft_plan *plan) { return plan->fast.kind && fast_f64in_kind(plan->fast.kind); }
+
 template <int N1, int N2, int NROWS, int MINW>
 static int32_t launch_wave(const pds_stft_plan *plan, const BatchArgs &a) {
   using G = WaveGeom<N1, N2, NROWS>;
   constexpr int CU_WAVES = 4 * MINW;  // resident waves per CU that the register budget allows
   const FastTables &ft = plan->fast;
   FastParams p;
-  p.sig = (const float *)a.d_signal;
+  p.sig = a.d_signal;
   p.offsets = a.d_offsets;
   p.lengths = a.d_lengths;
   p.nframes = a.d_nframes;
   p.row_off = a.d_row_off;
-  p.out = (float *)a.d_out;
+  p.out = a.d_out;
   p.out_stride = a.out_stride;
   p.win_lane = ft.d_window;
   p.tw_lane = (const float2 *)ft.d_twiddle;
@@ -1077,7 +1108,7 @@ static int32_t launch_wave(const pds_stft_plan *plan, const BatchArgs &a) {
   p.inv_L = 1.0f / (float)plan->d.frame_length;
   p.num_utts = a.B;
   const int64_t chunks = (a.max_frames + G::GROUPS - 1) / G::GROUPS;
-  if (chunks * a.B > 0x7fffffff || chunks > 0x3fffffff || a.out_stride * G::GROUPS > 0x1fffffff ||
+  if (chunks * a.B > 0x7fffffff || chunks > 0x3fffffff || a.out_stride * G::GROUPS > (a.out_f64 ? 0x0fffffff : 0x1fffffff) ||
       a.max_frames * plan->d.frame_shift > 0x7fffffff) {
     set_error("stft_batch: too many frame chunks in one call");
     return PDS_ERR_INVALID;
@@ -1104,7 +1135,7 @@ static int32_t launch_wave(const pds_stft_plan *plan, const BatchArgs &a) {
   int walk = 0;
   for (int cand = (G::GROUPS == 4) ? ft.walk : 0; cand >= 0 && !in_lds; --cand) {
     // (no segmented variant of the fused pre-emphasis kernel)
-    if ((cand == 2 && ft.rs_rounds == 0) || (cand == 1 && (ft.seg_rounds == 0 || pre))) continue;
+    if ((cand == 2 && ft.rs_rounds == 0) || (cand == 1 && (ft.seg_rounds == 0 || pre || a.in_f64))) continue;
     const int meta_ints = cand == 2 ? ft.rs_rounds * 64 : cand == 1 ? ft.seg_meta_ints : ft.ell_slots * N2;
     const int meta_pad = (std::max(meta_ints, USLOTS * N2) + 3) / 4 * 4;
     const size_t fixed = (size_t)N2 * 8 + (size_t)meta_pad * 4;
@@ -1144,6 +1175,7 @@ static int32_t launch_wave(const pds_stft_plan *plan, const BatchArgs &a) {
   // (dense complex bank at N >= 1024 plus pre-emphasis) takes the direct-DFT kernel
   if (pre && !in_lds) return launch_stft_generic_f32(plan, a);
   p.preemph = (float)a.preemph;
+  p.preemph_d = a.preemph;
   p.waves = waves;
   p.mf_tab = ft.d_mf_tab;
 #if PDS_STAMPS
@@ -1174,11 +1206,37 @@ static int32_t launch_wave(const pds_stft_plan *plan, const BatchArgs &a) {
                    : stft_wave_kernel<N1, N2, NROWS, CU_WAVES, MINW, true, false, false, MFS>;
     }
   }
+  // float64 samples (pds_stft_batch_f64in): the common power-of-two geometries, LDS-resident tables,
+  // ELL or row-segment walk; float64 features without fused pre-emphasis only
+  int f64_which = -1;
+  if (a.in_f64) {
+    constexpr bool F64IN = fast_f64in_kind(N1 * N2);
+    if constexpr (F64IN) {
+      if (!in_lds || (a.out_f64 && pre)) {
+        set_error("stft_batch_f64in: not served for this plan (filter table outside LDS, or float64 features with fused pre-emphasis)");
+        return PDS_ERR_INVALID;
+      }
+      mf = false;
+      if (a.out_f64)
+        kern = rsg ? stft_wave_kernel<N1, N2, NROWS, CU_WAVES, MINW, true, false, false, 0, W4, double, double>
+                   : stft_wave_kernel<N1, N2, NROWS, CU_WAVES, MINW, true, false, false, 0, false, double, double>;
+      else if (pre)
+        kern = rsg ? stft_wave_kernel<N1, N2, NROWS, CU_WAVES, MINW, true, true, false, 0, W4, double, float>
+                   : stft_wave_kernel<N1, N2, NROWS, CU_WAVES, MINW, true, true, false, 0, false, double, float>;
+      else
+        kern = rsg ? stft_wave_kernel<N1, N2, NROWS, CU_WAVES, MINW, true, false, false, 0, W4, double, float>
+                   : stft_wave_kernel<N1, N2, NROWS, CU_WAVES, MINW, true, false, false, 0, false, double, float>;
+      f64_which = 12 + (a.out_f64 ? 4 : pre ? 2 : 0) + (rsg ? 1 : 0);
+    } else {
+      set_error("stft_batch_f64in: no fused float64-input kernel for this transform size");
+      return PDS_ERR_INVALID;
+    }
+  }
   // the dynamic-LDS limit is an attribute of the kernel on one device: raised once per
   // (instantiation, device, variant) and remembered (relaxed atomics: a lost race repeats the call)
   constexpr int kDevices = 64;
-  static std::atomic<size_t> attr_smem[kDevices][12];
-  const int which = (pre ? (rsg ? 5 : 2) : rsg ? 4 : seg ? 3 : (in_lds ? 1 : 0)) + (mf ? 6 : 0);
+  static std::atomic<size_t> attr_smem[kDevices][18];
+  const int which = f64_which >= 0 ? f64_which : (pre ? (rsg ? 5 : 2) : rsg ? 4 : seg ? 3 : (in_lds ? 1 : 0)) + (mf ? 6 : 0);
   const bool cached = plan->device >= 0 && plan->device < kDevices;
   if (!cached || smem > attr_smem[plan->device][which].load(std::memory_order_relaxed)) {
     PDS_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize,

@@ -386,6 +386,63 @@ def test_float64_signals_can_opt_into_float32_arithmetic(computers, golden_stft,
     assert np.abs(fast - want).max() > 1e-9  # it really was float32 arithmetic
 
 
+@pytest.mark.parametrize("name", ["c2_tri_mel40", "c3_fbank80_energy", "c4_gabor64", "c5_gammatone64_48k"])
+def test_fused_float64_input_kernel(name, computers, golden_tables, master_signal, monkeypatch):
+    """pds_stft_batch_f64in: float64 samples straight into the fused kernel (rounded at the frame load),
+    float32 or float64 features -- no conversion pass over the signal (the launch must not call .to)"""
+    import torch
+
+    from pydrobert_speech_amd import config
+
+    comp = computers[name]
+    assert comp._native_plan().has_f64in
+    p = oracle_params(golden_tables, name)
+    lens = [0, 1, 150, comp.frame_length // 2 + 1, 2000, 16000, 4801]
+    sigs = [master_signal[100 : 100 + n].astype("f8") for n in lens]
+    want = [orc.compute_full(x, p) for x in sigs]
+    offs = np.concatenate([[0], np.cumsum(lens)[:-1]])
+    packed = torch.from_numpy(np.concatenate(sigs)).cuda()
+    layout = comp.prepare_layout(offs, lens, device=packed.device)
+    rows = layout.row_offsets
+    out32 = torch.empty((int(rows[-1]), comp.num_coeffs), dtype=torch.float32, device="cuda")
+    monkeypatch.setattr(config, "FLOAT64_ARITHMETIC", "float32")
+    monkeypatch.setattr(torch.Tensor, "to", lambda *a, **k: pytest.fail("the launch converted a tensor"))
+    feats64 = comp.launch(packed, layout)
+    feats32 = comp.launch(packed, layout, out=out32)
+    monkeypatch.undo()
+    assert feats64.dtype == torch.float64 and feats32.dtype == torch.float32
+    assert torch.equal(feats64, feats32.double())  # one kernel, two store widths
+    got = feats32.cpu().numpy()
+    for b, w in enumerate(want):
+        assert_features_close(got[rows[b] : rows[b + 1]], w, **F32)
+
+
+def test_fused_float64_input_with_preemphasis(computers, golden_tables, master_signal, monkeypatch):
+    # float64 samples are pre-emphasised in float64 before the rounding, like the reference's own pass
+    import torch
+
+    from pydrobert_speech_amd import config
+    from pydrobert_speech_amd.pre import Preemphasize
+
+    comp = computers["c2_tri_mel40"]
+    p = oracle_params(golden_tables, "c2_tri_mel40")
+    lens = [3000, 401, 16000]
+    sigs = [master_signal[7 : 7 + n].astype("f8") for n in lens]
+    offs = np.concatenate([[0], np.cumsum(lens)[:-1]])
+    packed = torch.from_numpy(np.concatenate(sigs)).cuda()
+    monkeypatch.setattr(config, "FLOAT64_ARITHMETIC", "float32")
+    out32 = torch.empty((sum(comp.num_frames(n) for n in lens), comp.num_coeffs), dtype=torch.float32, device="cuda")
+    feats, rows = comp.compute_packed(packed, offs, lens, preemphasis=0.97, out=out32)
+    wide, _ = comp.compute_packed(packed, offs, lens, preemphasis=0.97)
+    monkeypatch.undo()
+    assert wide.dtype == torch.float64 and torch.equal(wide, feats.double())
+    got = feats.cpu().numpy()
+    for b, x in enumerate(sigs):
+        y = x.copy()
+        y[1:] -= 0.97 * x[:-1]
+        assert_features_close(got[rows[b] : rows[b + 1]], orc.compute_full(y, p), rtol=2e-4, atol=2e-5)
+
+
 @pytest.mark.parametrize("name", ["c1_kaldi_fbank", "c2_tri_mel40", "v_tri_analytic_nolog", "v_gabor_nopad_mag"])
 def test_streaming_random_chunkings_match_reference_call_by_call(name, computers, master_signal):
     # tests/golden/make_golden_stream.py: eight lengths (one sample .. 4000) x random cut points;
