@@ -175,7 +175,7 @@ def parity_spot_check(comp, signal, offsets, lengths, layout, out, picks=3):
     )
     B, C = len(lengths), comp.num_coeffs
     worst_abs = worst_tol = 0.0
-    rows = 0
+    rows = floor_elems = 0
     utts = sorted({0, B // 2, B - 1})[:picks]
     for b in utts:
         x = signal[int(offsets[b]) : int(offsets[b] + lengths[b])].cpu().numpy()
@@ -187,11 +187,23 @@ def parity_spot_check(comp, signal, offsets, lengths, layout, out, picks=3):
         err = np.abs(got - want)
         if np.isnan(err).any():
             return {"pass": False, "error": f"utterance {b}: NaN"}
+        over = err / (1e-5 + 1e-4 * np.abs(want))
+        # float32 arithmetic: a coefficient 40 dB and more below its frame's largest one carries the
+        # transform's round-off at full size (tools/fuzz_parity.py); such an element
+        # counts as inside when its error is below 1e-6 of the frame's largest coefficient, linear domain
+        if comp._log:
+            lin_got, lin_want = np.exp(got), np.exp(want)
+        else:
+            lin_got, lin_want = got, want
+        floor = (over > 1.0) & (np.abs(lin_got - lin_want) <= 1e-6 * np.abs(lin_want).max(axis=1, keepdims=True))
+        floor_elems += int(floor.sum())
+        over = np.where(floor, 0.0, over)
         worst_abs = max(worst_abs, float(err.max()))
-        worst_tol = max(worst_tol, float((err / (1e-5 + 1e-4 * np.abs(want))).max()))
+        worst_tol = max(worst_tol, float(over.max()))
         rows += want.shape[0]
     return {"pass": worst_tol <= 1.0, "utterances": utts, "rows": rows, "coeffs": C, "max_abs_err": worst_abs,
             "max_err_over_tolerance": worst_tol, "tolerance": "1e-5 + 1e-4 |ref|",
+            "elements_at_the_float32_floor": floor_elems,
             "against": "oracle/stft_oracle.compute_full (float64) on the timed buffer's own input"}
 
 
@@ -230,6 +242,8 @@ def main():
     ap.add_argument("--dtype", default="f32", choices=["f32", "f64in"],
                     help="f64in: float64 samples in HBM, rounded to float32 by the fused kernel as it loads the "
                          "frames (pds_stft_batch_f64in), float32 features -- the reference drivers' dtype flow")
+    ap.add_argument("--fused-deltas", action="store_true",
+                    help="deltas2 workloads: statics and deltas by one launch (A/B against the two launches)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true")
     ap.add_argument("--generic", action="store_true",
@@ -326,6 +340,10 @@ def main():
         nonlocal cmvn_out
         if is_si:
             comp.compute_packed(signal, offsets, lengths, out=out, direct=args.generic)
+            return
+        if deltas is not None and args.fused_deltas and not args.generic and args.dtype == "f32":
+            # statics and deltas by one launch (pds_stft_deltas_batch_f32): measured slower than the two launches
+            comp.launch_with_deltas(signal, layout, deltas, out=out, fused=True)
             return
         comp.launch(signal, layout, out=out, generic=args.generic)
         if deltas is not None:  # statics were written with row stride 3C; deltas go beside them

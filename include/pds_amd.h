@@ -135,6 +135,22 @@ int32_t pds_stft_batch_f64in(const pds_stft_plan *plan, const double *d_signal,
                              const int64_t *d_nframes, const int64_t *d_row_off, int32_t B,
                              int64_t max_frames, int32_t pad_left, double preemph, void *d_out,
                              int32_t out_is_f64, int64_t out_stride, void *stream);
+/* Statics AND deltas in one launch (BASELINE.json configs[2]; reference post.py:462-491 applied to
+ * compute_full's output along time, "edge" padding): row r of utterance b receives the num_coeffs
+ * statics at columns [0, C) and the order-k deltas at [k C, (k + 1) C), k = 1 .. num_deltas.  The
+ * statics make no second trip through HBM: a workgroup differentiates the frames whose statics
+ * it has just stored (stft_fast.hip, DLT).  num_deltas 1 or 2, context_window 2; `taps`: HOST array
+ * of the filters exactly as the caller's Deltas object holds them -- 5 taps of order 1, then (if
+ * num_deltas = 2) the 9 taps of order 2 (numpy.convolve of the ramp with itself, post.py:456-460).
+ * Values equal pds_stft_batch_f32 followed by pds_deltas_rows_f32 bit for bit.  Served for plans
+ * with transform sizes 512 and 1024 and LDS-resident filter tables: pds_stft_plan_has_fused_deltas(). */
+int32_t pds_stft_plan_has_fused_deltas(const pds_stft_plan *plan);
+int32_t pds_stft_deltas_batch_f32(const pds_stft_plan *plan, const float *d_signal,
+                                  const int64_t *d_offsets, const int64_t *d_lengths,
+                                  const int64_t *d_nframes, const int64_t *d_row_off, int32_t B,
+                                  int64_t max_frames, int32_t pad_left, int32_t num_deltas,
+                                  int32_t context_window, const double *taps, float *d_out,
+                                  int64_t out_stride, void *stream);
 /* float32 input through the generic kernels regardless of N: radix-2 FFT in LDS for powers of two,
  * direct DFT otherwise (cross-check of the fused kernel; also what sizes without a fused geometry use) */
 int32_t pds_stft_batch_f32_generic(const pds_stft_plan *plan, const float *d_signal,

@@ -197,6 +197,7 @@ class _NativePlan:
         self.handle = handle
         self.kernel_kind = lib.pds_stft_plan_kernel_kind(handle)
         self.has_f64in = bool(lib.pds_stft_plan_has_f64in(handle))
+        self.has_fused_deltas = bool(lib.pds_stft_plan_has_fused_deltas(handle))
 
     def __del__(self):
         handle, self.handle = getattr(self, "handle", None), None
@@ -488,6 +489,60 @@ class ShortTimeFourierTransformFrameComputer(LinearFilterBankFrameComputer):
                 )
                 _native.check(rc, "pds_stft_batch")
         return out
+
+    def launch_with_deltas(self, signal, layout: "PackedLayout", deltas, out=None, pad_left=None,
+                           fused: bool = False):
+        """Statics and ``deltas`` (a :class:`pydrobert_speech_amd.post.Deltas`) of a packed batch
+
+        Returns the ``(total_rows, (K + 1) num_coeffs)`` float32 tensor: row r holds the features of
+        frame r followed by its order-1 .. order-K deltas: :func:`launch` into rows of that stride
+        followed by ``deltas.apply_rows``.  ``fused=True`` asks for the one-launch form
+        (``pds_stft_deltas_batch_f32``: transform sizes 512 and 1024, ``Deltas(1 or 2)`` with the
+        default context window and padding; same values bit for bit) -- measured 10 % SLOWER than
+        the two launches on an MI355X, so it is not the default.
+        """
+        torch = _native.require_device()
+        lib = _native.lib()
+        C, K = self.num_coeffs, deltas.num_deltas
+        total = layout.total_rows
+        if out is None:
+            out = torch.empty((total, (K + 1) * C), dtype=torch.float32, device=signal.device)
+        elif (out.dtype != torch.float32 or out.dim() != 2 or out.shape[0] < total or out.shape[1] < (K + 1) * C
+              or out.stride(1) != 1):
+            raise ValueError("out has the wrong dtype, shape or strides")
+        plan = self._native_plan(signal.device)
+        filts = deltas._filts[1:]
+        fused = (
+            fused and plan.has_fused_deltas and signal.dtype == torch.float32 and K in (1, 2) and deltas.concatenate
+            and deltas._pad_mode == "edge" and not deltas._pad_kwargs
+            and [len(f) for f in filts] == [5, 9][:K] and total > 0
+        )
+        if fused:
+            if not signal.is_cuda or signal.dim() != 1 or not signal.is_contiguous():
+                raise ValueError("signal must be a contiguous 1-D tensor on the GPU")
+            if layout.extent > signal.numel():
+                raise ValueError("an utterance lies outside the signal buffer")
+            taps = np.ascontiguousarray(np.concatenate(filts), dtype=np.float64)
+            stream = torch.cuda.current_stream(signal.device).cuda_stream
+            pad = -1 if pad_left is None else int(pad_left)
+            meta = layout.d_meta
+            with torch.cuda.device(signal.device):
+                for lo in range(0, layout.B, _MAX_UTTS_PER_CALL):
+                    hi = min(layout.B, lo + _MAX_UTTS_PER_CALL)
+                    rc = lib.pds_stft_deltas_batch_f32(
+                        plan.handle, signal.data_ptr(), meta[0, lo:].data_ptr(), meta[1, lo:].data_ptr(),
+                        meta[2, lo:].data_ptr(), meta[3, lo:].data_ptr(), hi - lo, int(layout.nframes[lo:hi].max()),
+                        pad, K, 2, taps.ctypes.data, out.data_ptr(), out.stride(0), stream,
+                    )
+                    if rc != 0 and lo == 0:
+                        fused = False  # (e.g. a filter table that does not fit in LDS): the two launches below
+                        break
+                    _native.check(rc, "pds_stft_deltas_batch")
+        if not fused:
+            self.launch(signal, layout, out=out, pad_left=pad_left)
+            if total:
+                deltas.apply_rows(out[:, :C], layout.row_offsets, out=out)
+        return out[:, : (K + 1) * C] if out.shape[1] != (K + 1) * C else out
 
     def compute_packed(self, signal, offsets, lengths, nframes=None, pad_left=None, out=None,
                        generic=False, preemphasis: float = 0.0):

@@ -115,6 +115,9 @@ struct BatchArgs {
   // fused kernel only: float64 samples rounded at the frame load / float64 features widened at the
   // store (float32 arithmetic either way); pds_stft_batch_f64in
   bool in_f64 = false, out_f64 = false;
+  // fused statics + deltas (pds_stft_deltas_batch_f32): order (0 = none) and the taps, order 1 then 2
+  int dl_K = 0;
+  double dl_taps[16] = {0};
 };
 
 // stft_generic.hip
@@ -126,6 +129,7 @@ int32_t fast_tables_create(pds_stft_plan *plan, const double *window, const int3
 void fast_tables_destroy(pds_stft_plan *plan);
 int32_t launch_stft_fast_f32(const pds_stft_plan *plan, const BatchArgs &a);
 bool fast_has_f64in(const pds_stft_plan *plan);
+bool fast_has_fused_deltas(const pds_stft_plan *plan);
 
 // Runs `body` (plan construction: host allocations) so that no C++ exception crosses the C ABI.
 template <typename F>

@@ -125,6 +125,11 @@ struct FastParams {
   int waves;  // wavefronts per workgroup of this launch (<= MAXWAVES)
   const float *mf_tab;  // matrix-pipe front end (MF instantiations): image of MfmaFrontTables
   unsigned long long *stamps;  // diagnostic builds (PDS_STAMPS): [grid waves][8] phase times, else null
+  // fused statics + deltas launches (DLT instantiations): a workgroup takes whole runs of chunks of one
+  // utterance and computes the deltas of the run's frames itself once its statics are written
+  int run_len, runs_per_utt, total_runs;  // chunks per run (without the two halo chunks), runs per utterance
+  int dl_inner;                           // coefficients per frame to differentiate (= num_coeffs)
+  double dl_taps[16];                     // order-1 taps (2 W + 1) followed by the order-2 taps (4 W + 1), W = 2
   int step_utts, step_chunks;  // (grid waves) / chunks_per_utt and (grid waves) % chunks_per_utt
 };
 
@@ -172,6 +177,65 @@ __device__ __forceinline__ void wave_sync() {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// Deltas of the frames [f_lo, f_hi) of one utterance (T frames, rows of out_stride floats starting at
+// `rows`), by all threads of the workgroup: the fused launches' epilogue of a run (stft_wave_kernel,
+// DLT).  As post.hip's register-window kernel: a thread owns 8 consecutive frames of one coefficient,
+// reads the 8 + 2 K W statics it needs once (edge clamp in the frame index, reference post.py:447,
+// 470-483), and accumulates in float64 with separately rounded multiplies and adds, so the values
+// are numpy's bit for bit.  Order k goes to columns [k C, (k + 1) C) of the frame's row.
+template <int K>
+__device__ __forceinline__ void deltas_of_run(const FastParams &p, float *rows, int T, int f_lo, int f_hi) {
+  // (this file is compiled with -ffp-contract=fast, under which the backend fuses whatever it meets,
+  // and HIP's __dmul_rn is a plain multiply: the products go through asm so that they are rounded
+  // before the sums, as numpy rounds them)
+  auto mul = [](double a, double b) {
+    double t;
+    asm("v_mul_f64 %0, %1, %2" : "=v"(t) : "v"(a), "v"(b));
+    return t;
+  };
+  constexpr int W = 2, H = K * W, R = 8, NV = R + 2 * H;
+  const int C = p.dl_inner;
+  const int64_t stride = p.out_stride;
+  const int items = (f_hi - f_lo + R - 1) / R * C;
+  double f1[2 * W + 1], f2[4 * W + 1];
+#pragma unroll
+  for (int j = 0; j < 2 * W + 1; ++j) f1[j] = p.dl_taps[j];
+#pragma unroll
+  for (int j = 0; j < 4 * W + 1; ++j) f2[j] = p.dl_taps[2 * W + 1 + j];
+  for (int e = threadIdx.x; e < items; e += blockDim.x) {
+    const int grp = e / C, i = e - grp * C, t0 = f_lo + grp * R;
+    double v[NV];
+    if (t0 >= H && t0 + R + H <= T) {
+      const float *c = rows + (int64_t)(t0 - H) * stride + i;
+#pragma unroll
+      for (int q = 0; q < NV; ++q) v[q] = (double)c[q * stride];
+    } else {
+#pragma unroll
+      for (int q = 0; q < NV; ++q) {
+        int t = t0 - H + q;
+        t = t < 0 ? 0 : (t >= T ? T - 1 : t);
+        v[q] = (double)rows[(int64_t)t * stride + i];
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < R; ++q) {
+      if (t0 + q < f_hi) {
+        float *orow = rows + (int64_t)(t0 + q) * stride + i;
+        double acc = 0.0;
+#pragma unroll
+        for (int j = 0; j < 2 * W + 1; ++j) acc += mul(f1[j], v[H + q + j - W]);
+        orow[C] = (float)acc;
+        if constexpr (K == 2) {
+          acc = 0.0;
+#pragma unroll
+          for (int j = 0; j < 4 * W + 1; ++j) acc += mul(f2[j], v[H + q + j - 2 * W]);
+          orow[2 * C] = (float)acc;
+        }
+      }
+    }
+  }
 }
 
 // N = N1 * N2: in-lane real DFT size x lanes per frame.  NROWS = ceil(L / N2) rows of N2
@@ -234,8 +298,18 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // of the reference's drivers (float64 audio in, compute.py:601 output dtype = input dtype) without
 // separate conversion passes over the signal and the features.
 template <int N1, int N2, int NROWS, int MAXWAVES, int MINW, bool ELL_LDS, bool PRE, bool SEG = false, int MF = 0,
-          bool RSG = false, typename TIN = float, typename TOUT = float>
+          bool RSG = false, typename TIN = float, typename TOUT = float, int DLT = 0>
 __global__ __launch_bounds__(MAXWAVES * 64, MINW) void stft_wave_kernel(const FastParams p) {
+  // DLT = K > 0: Deltas(K, context_window 2) of the features appended to every row by the same launch
+  // (reference post.py:462-491; BASELINE.json configs[2]).  Work is dealt in RUNS: workgroup w takes
+  // runs w, w + grid, ...; a run is run_len consecutive chunks of one utterance plus one halo chunk
+  // on either side (four frames: the reach of the order-2 filter), whose statics the workgroup
+  // computes and stores itself -- a neighbouring run stores the same values again -- so that after
+  // ONE workgroup barrier every static its deltas need was written by this very CU and is read back
+  // through its own L1 / L2.  The statics never make a second trip to HBM and no second kernel reads
+  // them with a row stride that wastes two thirds of every line.
+  static_assert(DLT == 0 || (DLT <= 2 && N2 == 16 && std::is_same<TOUT, float>::value && MF == 0),
+                "fused deltas: order 1 or 2, 16-lane geometries, float32 features");
   static_assert(MF == 0 || std::is_same<TIN, float>::value, "matrix-pipe front end: float32 samples");
   using G = WaveGeom<N1, N2, NROWS>;
   constexpr int N = G::N, COLS = G::COLS, NREG = G::NREG, RS = G::RS, NB = G::NB, PSTR = G::PSTR;
@@ -322,27 +396,70 @@ __global__ __launch_bounds__(MAXWAVES * 64, MINW) void stft_wave_kernel(const Fa
   if ((gridDim.x & 7) == 0) wg = (wg & 7) * (gridDim.x >> 3) + (wg >> 3);
 #endif
   int chunk = wg * p.waves + wave;
-  while (chunk >= p.chunks_per_utt && b < p.num_utts) {  // once per kernel
-    chunk -= p.chunks_per_utt;
-    ++b;
+  if constexpr (DLT == 0) {
+    while (chunk >= p.chunks_per_utt && b < p.num_utts) {  // once per kernel
+      chunk -= p.chunks_per_utt;
+      ++b;
+    }
   }
   // The utterance record of an item (frame count, length, signal offset, output row) is fetched
   // during the filter phase of the item before: four dependent scalar-load round trips at the
   // top of every item otherwise.
   int nfr = 0, n = 0;
   int64_t sig_off = 0, out_row = 0;
-  if (b < p.num_utts) {
+  if (DLT == 0 && b < p.num_utts) {
     nfr = (int)load_const(p.nframes + b);  // (frame and sample counts fit an int: host check)
     n = (int)load_const(p.lengths + b);
     sig_off = load_const(p.offsets + b);
     out_row = load_const(p.row_off + b);
   }
+  // (DLT) the run in hand: chunks [c_lo, c_hi) incl. halos, deltas for frames [f_lo, f_hi)
+  [[maybe_unused]] int run = wg - (int)gridDim.x, c_hi = 0, f_lo = 0, f_hi = 0;
+  [[maybe_unused]] bool run_open = false;
+  if constexpr (DLT > 0) chunk = 0;
   if constexpr (PDS_STAGGER) {
     if (b < p.num_utts && (wave & 4)) __builtin_amdgcn_s_barrier();
   }
   [[maybe_unused]] unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   [[maybe_unused]] unsigned long long st_prev = PDS_STAMPS ? __builtin_readcyclecounter() : 0;
-  while (b < p.num_utts) {
+  while (DLT > 0 || b < p.num_utts) {
+    if constexpr (DLT > 0) {
+      // every wave of the workgroup walks the same runs and meets the others once per run, whether
+      // or not any of the run's chunks fell to it
+      bool finished = false;
+      while (chunk >= c_hi) {
+        if (run_open) {
+          // every wave's statics must have left for L2 before anyone reads them back: drain this
+          // wave's stores, meet the others, and drop what this CU's L1 may still hold of those lines
+          // (their delta columns were read by an earlier run's epilogue).  Once per run: ~2 us.
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          __builtin_amdgcn_s_barrier();
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+          deltas_of_run<DLT>(p, static_cast<float *>(p.out) + out_row * p.out_stride, nfr, f_lo, f_hi);
+          run_open = false;
+        }
+        run += (int)gridDim.x;
+        if (run >= p.total_runs) {
+          finished = true;
+          break;
+        }
+        b = run / p.runs_per_utt;
+        const int j = run - b * p.runs_per_utt;
+        nfr = (int)load_const(p.nframes + b);
+        n = (int)load_const(p.lengths + b);
+        sig_off = load_const(p.offsets + b);
+        out_row = load_const(p.row_off + b);
+        const int chunks_b = (nfr + G::GROUPS - 1) / G::GROUPS;
+        const int c_lo = j * p.run_len > 0 ? j * p.run_len - 1 : 0;
+        c_hi = (j + 1) * p.run_len + 1 < chunks_b ? (j + 1) * p.run_len + 1 : chunks_b;
+        f_lo = j * p.run_len * G::GROUPS;
+        f_hi = (j + 1) * p.run_len * G::GROUPS < nfr ? (j + 1) * p.run_len * G::GROUPS : nfr;
+        chunk = c_lo + wave;
+        run_open = f_lo < f_hi;
+        if (!run_open) c_hi = 0;  // (nothing of this utterance in the run: ragged batches)
+      }
+      if (finished) break;
+    }
     int nchunk = chunk + p.step_chunks, nb = b + p.step_utts;
     if (nchunk >= p.chunks_per_utt) {
       nchunk -= p.chunks_per_utt;
@@ -350,7 +467,7 @@ __global__ __launch_bounds__(MAXWAVES * 64, MINW) void stft_wave_kernel(const Fa
     }
     const int pb = nb < p.num_utts ? nb : b;  // record to fetch (any valid one past the end)
     const int tb = chunk * G::GROUPS;  // first frame of the chunk (frames * S fits an int)
-    if (tb >= nfr) {  // uniform: utterance shorter than the longest
+    if (DLT == 0 && tb >= nfr) {  // uniform: utterance shorter than the longest
       b = nb;
       chunk = nchunk;
       nfr = (int)load_const(p.nframes + pb);
@@ -852,12 +969,16 @@ __global__ __launch_bounds__(MAXWAVES * 64, MINW) void stft_wave_kernel(const Fa
     wave_sync();
     [[maybe_unused]] const int frames_here = nfr - tb;  // frames of this chunk that exist (SEG)
     // this item's record is dead from here on: fetch the next one under the filter phase
-    b = nb;
-    chunk = nchunk;
-    nfr = (int)load_const(p.nframes + pb);
-    n = (int)load_const(p.lengths + pb);
-    sig_off = load_const(p.offsets + pb);
-    out_row = load_const(p.row_off + pb);
+    if constexpr (DLT > 0) {
+      chunk += p.waves;  // (the run's record stays)
+    } else {
+      b = nb;
+      chunk = nchunk;
+      nfr = (int)load_const(p.nframes + pb);
+      n = (int)load_const(p.lengths + pb);
+      sig_off = load_const(p.offsets + pb);
+      out_row = load_const(p.row_off + pb);
+    }
 
     auto run_slot = [&](const int meta, const int len, const int slot_woff_) {
       const float4 *prow = reinterpret_cast<const float4 *>(Pg + (meta & 0xffff));
@@ -1076,6 +1197,11 @@ constexpr bool fast_f64in_kind(int n) { return n == 256 || n == 512 || n == 1024
 
 bool fast_has_f64in(const pds_stft_plan *plan) { return plan->fast.kind && fast_f64in_kind(plan->fast.kind); }
 
+// transform sizes with fused statics + deltas instantiations (16-lane geometries)
+constexpr bool fast_deltas_kind(int n) { return n == 512 || n == 1024; }
+
+bool fast_has_fused_deltas(const pds_stft_plan *plan) { return plan->fast.kind && fast_deltas_kind(plan->fast.kind); }
+
 template <int N1, int N2, int NROWS, int MINW>
 static int32_t launch_wave(const pds_stft_plan *plan, const BatchArgs &a) {
   using G = WaveGeom<N1, N2, NROWS>;
@@ -1232,11 +1358,37 @@ static int32_t launch_wave(const pds_stft_plan *plan, const BatchArgs &a) {
       return PDS_ERR_INVALID;
     }
   }
+  // fused statics + deltas (pds_stft_deltas_batch_f32): run scheduling, see the kernel
+  int dl_which = -1;
+  if (a.dl_K > 0) {
+    constexpr bool DELTAS = fast_deltas_kind(N1 * N2) && G::GROUPS == 4;
+    if constexpr (DELTAS) {
+      if (!in_lds || pre || a.in_f64 || seg) {
+        set_error("stft_deltas_batch: not served for this plan and call (filter table outside LDS, segmented walk, "
+                  "fused pre-emphasis or float64 samples)");
+        return PDS_ERR_INVALID;
+      }
+      mf = false;
+      kern = a.dl_K == 1
+                 ? (rsg ? stft_wave_kernel<N1, N2, NROWS, CU_WAVES, MINW, true, false, false, 0, true, float, float, 1>
+                        : stft_wave_kernel<N1, N2, NROWS, CU_WAVES, MINW, true, false, false, 0, false, float, float, 1>)
+                 : (rsg ? stft_wave_kernel<N1, N2, NROWS, CU_WAVES, MINW, true, false, false, 0, true, float, float, 2>
+                        : stft_wave_kernel<N1, N2, NROWS, CU_WAVES, MINW, true, false, false, 0, false, float, float, 2>);
+      dl_which = 18 + (a.dl_K - 1) * 2 + (rsg ? 1 : 0);
+      for (int j = 0; j < 16; ++j) p.dl_taps[j] = a.dl_taps[j];
+      p.dl_inner = plan->d.num_filts + (plan->d.include_energy ? 1 : 0);
+    } else {
+      set_error("stft_deltas_batch: no fused kernel for this transform size");
+      return PDS_ERR_INVALID;
+    }
+  }
   // the dynamic-LDS limit is an attribute of the kernel on one device: raised once per
   // (instantiation, device, variant) and remembered (relaxed atomics: a lost race repeats the call)
   constexpr int kDevices = 64;
-  static std::atomic<size_t> attr_smem[kDevices][18];
-  const int which = f64_which >= 0 ? f64_which : (pre ? (rsg ? 5 : 2) : rsg ? 4 : seg ? 3 : (in_lds ? 1 : 0)) + (mf ? 6 : 0);
+  static std::atomic<size_t> attr_smem[kDevices][22];
+  const int which = dl_which >= 0    ? dl_which
+                    : f64_which >= 0 ? f64_which
+                                     : (pre ? (rsg ? 5 : 2) : rsg ? 4 : seg ? 3 : (in_lds ? 1 : 0)) + (mf ? 6 : 0);
   const bool cached = plan->device >= 0 && plan->device < kDevices;
   if (!cached || smem > attr_smem[plan->device][which].load(std::memory_order_relaxed)) {
     PDS_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1249,6 +1401,23 @@ static int32_t launch_wave(const pds_stft_plan *plan, const BatchArgs &a) {
   const int64_t grid_waves = grid * waves;
   p.step_utts = (int)(grid_waves / chunks);
   p.step_chunks = (int)(grid_waves % chunks);
+  p.run_len = p.runs_per_utt = p.total_runs = 0;
+  if (a.dl_K > 0) {
+    // runs: about two per workgroup of a full grid, at least 8 chunks (the two halo chunks are
+    // computed twice), at most an utterance
+    const int64_t full = (int64_t)ft.num_cus * wgs_per_cu;
+    int64_t run_len = (chunks * a.B + 2 * full - 1) / (2 * full);
+    run_len = std::min<int64_t>(std::max<int64_t>(run_len, 8), chunks);
+    const int64_t per_utt = (chunks + run_len - 1) / run_len;
+    if (per_utt * a.B > 0x7fffffff) {
+      set_error("stft_deltas_batch: too many runs in one call");
+      return PDS_ERR_INVALID;
+    }
+    p.run_len = (int)run_len;
+    p.runs_per_utt = (int)per_utt;
+    p.total_runs = (int)(per_utt * a.B);
+    grid = std::min<int64_t>(full, p.total_runs);
+  }
   hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(waves * 64), smem, a.stream, p);
   PDS_HIP(hipGetLastError());
   return PDS_OK;

@@ -371,3 +371,74 @@ def test_deltas_pad_modes_match_reference_outputs(name, kwargs):
             assert np.allclose(got, want, rtol=tol, atol=tol), (name, dt, np.abs(got - want).max())
             on_gpu = Deltas(2, context_window=2, target_axis=-1, **kwargs).apply(torch.from_numpy(x).cuda(), axis=0)
             assert on_gpu.is_cuda and np.allclose(on_gpu.cpu().numpy(), want, rtol=tol, atol=tol)
+
+
+@pytest.mark.parametrize("K", [1, 2])
+@pytest.mark.parametrize("bank", ["fbank80_energy", "mel40", "gammatone_1024"])
+def test_fused_statics_and_deltas_launch(K, bank):
+    """pds_stft_deltas_batch_f32 (one launch, run scheduling, deltas from the workgroup's own statics)
+    against the two launches: bit for bit, on a ragged batch with empty, one-frame and long utterances"""
+    import torch
+
+    from pydrobert_speech_amd.alias import alias_factory_subclass_from_arg
+    from pydrobert_speech_amd.compute import FrameComputer
+
+    cfg = {
+        "fbank80_energy": {"name": "stft", "bank": {"name": "fbank", "num_filts": 80}, "frame_length_ms": 25,
+                           "include_energy": True, "use_power": True},
+        "mel40": {"name": "stft", "bank": {"name": "tri", "scaling_function": "mel", "num_filts": 40},
+                  "frame_length_ms": 25, "frame_shift_ms": 10, "use_power": True},
+        "gammatone_1024": {"name": "stft", "bank": {"name": "gammatone", "scaling_function": "mel", "num_filts": 24,
+                                                    "sampling_rate": 48000}, "frame_length_ms": 20, "use_power": True},
+    }[bank]
+    comp = alias_factory_subclass_from_arg(FrameComputer, cfg)
+    assert comp._native_plan().has_fused_deltas
+    rng = np.random.default_rng(K)
+    S = comp.frame_shift
+    lens = [0, S, 5 * S, 9 * S + 3, 160000, 33 * S, 1, 4 * S, 57000, 12 * S, 100 * S + 7]
+    x = torch.from_numpy((3000 * rng.standard_normal(sum(lens))).astype("f4")).cuda()
+    offs = np.concatenate([[0], np.cumsum(lens)[:-1]])
+    layout = comp.prepare_layout(offs, lens, device=x.device)
+    C = comp.num_coeffs
+    deltas = Deltas(K)
+    fused = comp.launch_with_deltas(x, layout, deltas, fused=True)
+    assert fused.shape == (layout.total_rows, (K + 1) * C)
+    two = torch.empty_like(fused)
+    comp.launch(x, layout, out=two)
+    deltas.apply_rows(two[:, :C], layout.row_offsets, out=two)
+    assert torch.equal(fused, two)
+    # into a wider buffer; and many short utterances (more runs than workgroups, runs of one utterance each)
+    wide = torch.full((layout.total_rows, (K + 1) * C + 5), -7.0, device="cuda")
+    got = comp.launch_with_deltas(x, layout, deltas, out=wide, fused=True)
+    assert torch.equal(got, two) and bool((wide[:, (K + 1) * C :] == -7.0).all())
+    B = 1500
+    lens = rng.integers(0, 40 * S, size=B)
+    x = torch.from_numpy((3000 * rng.standard_normal(int(lens.sum()))).astype("f4")).cuda()
+    offs = np.concatenate([[0], np.cumsum(lens)[:-1]])
+    layout = comp.prepare_layout(offs, lens, device=x.device)
+    fused = comp.launch_with_deltas(x, layout, deltas, fused=True)
+    two = torch.empty_like(fused)
+    comp.launch(x, layout, out=two)
+    deltas.apply_rows(two[:, :C], layout.row_offsets, out=two)
+    assert torch.equal(fused, two)
+
+
+def test_launch_with_deltas_falls_back_to_two_launches():
+    # a context window the fused kernel does not have, and float64 samples
+    import torch
+
+    from pydrobert_speech_amd.alias import alias_factory_subclass_from_arg
+    from pydrobert_speech_amd.compute import FrameComputer
+
+    comp = alias_factory_subclass_from_arg(FrameComputer, {"name": "stft", "bank": "fbank", "frame_length_ms": 25})
+    rng = np.random.default_rng(3)
+    lens = [4000, 801, 16000]
+    x = torch.from_numpy((3000 * rng.standard_normal(sum(lens))).astype("f4")).cuda()
+    layout = comp.prepare_layout(np.concatenate([[0], np.cumsum(lens)[:-1]]), lens, device=x.device)
+    C = comp.num_coeffs
+    d3 = Deltas(2, context_window=3)
+    got = comp.launch_with_deltas(x, layout, d3, fused=True)
+    want = torch.empty_like(got)
+    comp.launch(x, layout, out=want)
+    d3.apply_rows(want[:, :C], layout.row_offsets, out=want)
+    assert torch.equal(got, want)
