@@ -1408,6 +1408,8 @@ static int32_t launch_wave(const pds_stft_plan *plan, const BatchArgs &a) {
     const int64_t full = (int64_t)ft.num_cus * wgs_per_cu;
     int64_t run_len = (chunks * a.B + 2 * full - 1) / (2 * full);
     run_len = std::min<int64_t>(std::max<int64_t>(run_len, 8), chunks);
+    if (const char *force = std::getenv("PDS_RUN_LEN"))  // (measurement: statics of shorter runs stay in cache)
+      run_len = std::min<int64_t>(std::max<int64_t>(std::atol(force), 2), chunks);
     const int64_t per_utt = (chunks + run_len - 1) / run_len;
     if (per_utt * a.B > 0x7fffffff) {
       set_error("stft_deltas_batch: too many runs in one call");
