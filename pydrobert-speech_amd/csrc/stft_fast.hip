@@ -96,6 +96,15 @@ extern "C" __attribute__((visibility("default"))) void pds_debug_set_stamp_buffe
 #ifndef PDS_STAGGER
 #define PDS_STAGGER 0
 #endif
+// filter-walk depth of the geometries that run two waves per SIMD or fewer (256 registers and more)
+// (measured, tools/ab_libs.sh: segmented walk four steps deep at N = 1024, Gammatone-64 +3 %; ELL walk four
+// steps deep: N = 4096 +0.6 %, N = 2048 -0.5 %)
+#ifndef PDS_SEG_DEEP_N
+#define PDS_SEG_DEEP_N 1024
+#endif
+#ifndef PDS_ELL_DEEP_N
+#define PDS_ELL_DEEP_N 4096
+#endif
 #ifndef PDS_FILTER_UNROLL
 #define PDS_FILTER_UNROLL 2
 #endif
@@ -1008,10 +1017,25 @@ __global__ __launch_bounds__(MAXWAVES * 64, MINW) void stft_wave_kernel(const Fa
         prow += 2;
       };
       const unsigned steps = (PDS_ABLATE & 32) ? 1u : (unsigned)len >> 3;
+      if constexpr (N >= PDS_ELL_DEEP_N) {
+        // (256-register geometries: four steps per pass, 16 reads in flight)
 #pragma unroll 1
-      for (unsigned i = steps >> 1; i != 0; --i) {
-        step();
-        step();
+        for (unsigned i = steps >> 2; i != 0; --i) {
+          step();
+          step();
+          step();
+          step();
+        }
+        if (steps & 2u) {
+          step();
+          step();
+        }
+      } else {
+#pragma unroll 1
+        for (unsigned i = steps >> 1; i != 0; --i) {
+          step();
+          step();
+        }
       }
       if (steps & 1u) step();
       float acc = (acc0 + acc1) + (acc2 + acc3);
@@ -1111,6 +1135,7 @@ __global__ __launch_bounds__(MAXWAVES * 64, MINW) void stft_wave_kernel(const Fa
         // part of the wave's area that P leaves free; then lane f adds up filter f's segments for
         // the four frames and stores four coefficients (64 consecutive floats per store).
         float4 *part = reinterpret_cast<float4 *>(wbase + G::GROUPS * PSTR);
+        constexpr int SEG_DEPTH = N >= PDS_SEG_DEEP_N ? 4 : 2;
         const int steps = p.seg_len >> 2;
         for (int q = 0; q < p.seg_rounds; ++q) {
           const int slot = q * 64 + lane;
@@ -1121,7 +1146,8 @@ __global__ __launch_bounds__(MAXWAVES * 64, MINW) void stft_wave_kernel(const Fa
           const float4 *p2 = reinterpret_cast<const float4 *>(wbase + 2 * PSTR + first);
           const float4 *p3 = reinterpret_cast<const float4 *>(wbase + 3 * PSTR + first);
           float4 acc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-#pragma unroll 2
+          // (geometries with the 256-register budget keep twice as many reads in flight)
+#pragma unroll SEG_DEPTH
           for (int i = 0; i < steps; ++i) {
             const float4 w = wrow[i];
             const float4 x0 = p0[i], x1 = p1[i], x2 = p2[i], x3 = p3[i];
