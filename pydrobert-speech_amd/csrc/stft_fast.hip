@@ -1711,7 +1711,10 @@ int32_t fast_tables_create(pds_stft_plan *plan, const double *window, const int3
     const char *force = std::getenv("PDS_STFT_WALK");
     ft.walk = ft.seg_rounds > 0 ? 1 : 0;  // (the segmented walk's own criterion, above)
     const long other = ft.walk == 1 ? ft.seg_reads : ft.ell_reads;
-    if (ft.rs_rounds > 0 && ft.rs_reads < other) ft.walk = 2;
+    // (measured: 40 mel filters, 15 reads in one round against 32: +5 %; 80 mel filters, 20 in two rounds
+    // against 32: +2 %; Gabor-64, 45 in three rounds against the segmented walk's 48: -1 ... -5 %: every
+    // round has an epilogue of its own)
+    if (ft.rs_rounds > 0 && 10 * ft.rs_reads <= 7 * other) ft.walk = 2;
     if (force && std::strcmp(force, "ell") == 0) ft.walk = 0;
     if (force && std::strcmp(force, "seg") == 0) ft.walk = ft.seg_rounds > 0 ? 1 : 0;
     if (force && std::strcmp(force, "rseg") == 0) ft.walk = ft.rs_rounds > 0 ? 2 : ft.walk;
