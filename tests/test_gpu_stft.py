@@ -530,3 +530,39 @@ def test_segmented_and_ell_filter_walks_agree(bank, monkeypatch):
     for a, b in zip(outs["0"], outs["1"]):
         assert a.shape == b.shape
         np.testing.assert_allclose(a, b, rtol=2e-5, atol=2e-5 * (np.abs(a).max() if a.size else 1))
+
+
+@pytest.mark.parametrize("switch,value", [("PDS_STFT_FRONT", "mfma"), ("PDS_STFT_WALK", "ell"), ("PDS_STFT_WALK", "seg"),
+                                          ("PDS_STFT_WALK", "rseg"), ("PDS_STFT_WAVES", "20")])
+@pytest.mark.parametrize("name", ["c1_readme_fbank", "c2_tri_mel40", "c3_fbank80_energy", "c4_gabor64"])
+def test_alternative_kernel_forms_match_the_oracle(switch, value, name, golden_meta, golden_tables, master_signal,
+                                                   monkeypatch):
+    """The forms a plan does not pick by default -- matrix-pipe front end, each of the three filter walks,
+    the half-exchange instantiation -- through the same ragged batch (switches are read when the plan is
+    created, so the computer is built after the switch is set)"""
+    monkeypatch.setenv(switch, value)
+    comp = alias_factory_subclass_from_arg(FrameComputer, json.loads(json.dumps(golden_meta["configs"][name])))
+    p = oracle_params(golden_tables, name)
+    lens = [0, 150, comp.frame_length // 2 + 1, 401, 2000, 16000, 4801, 7]
+    sigs = [master_signal[33 : 33 + n].astype("f4") for n in lens]
+    feats = comp.compute_full_batch(sigs)
+    for x, y in zip(sigs, feats):
+        assert_features_close(y, orc.compute_full(x, p), **F32)
+    # with fused pre-emphasis too (its own instantiations)
+    import torch
+
+    offs = np.concatenate([[0], np.cumsum(lens)[:-1]])
+    got, rows = comp.compute_packed(torch.from_numpy(np.concatenate(sigs)).cuda(), offs, lens, preemphasis=0.97)
+    got = got.cpu().numpy()
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("fuzz_parity", os.path.join(GOLDEN, "..", "..", "tools", "fuzz_parity.py"))
+    fuzz = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fuzz)
+    close = fuzz.close  # (knows the float32 floor: pre-emphasised noise empties the lowest bins)
+
+    for b, x in enumerate(sigs):
+        y = x.astype("f8")
+        y[1:] -= 0.97 * x[:-1].astype("f8")
+        ok, msg = close(got[rows[b] : rows[b + 1]], orc.compute_full(y.astype("f4"), p), 2e-4, 2e-5, is_log=True)
+        assert ok, (name, switch, value, b, msg)
