@@ -42,7 +42,6 @@ struct FastTables {
   float *d_rs_w = nullptr;         // [rs_rounds][rs_len / 4][64][4]
   int32_t *d_rs_meta = nullptr;    // [rs_rounds * 64]
   int rs_rounds = 0, rs_len = 0, rs_wfloats = 0;
-  bool waves20 = false;  // experiment (PDS_STFT_WAVES=20): five waves per SIMD at 32 x 16 (half exchange area)
   int walk = 0;  // preferred filter walk: 0 ELL, 1 segments (dense banks), 2 row segments
   long rs_reads = 0, rs_cost = 0, ell_reads = 0, seg_reads = 0;  // 16-byte LDS reads per lane and item of each walk
   // matrix-pipe front end (mfma_front.h; 32 x 16 geometry): device image of the tables, built for

@@ -307,11 +307,8 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // of the reference's drivers (float64 audio in, compute.py:601 output dtype = input dtype) without
 // separate conversion passes over the signal and the features.
 template <int N1, int N2, int NROWS, int MAXWAVES, int MINW, bool ELL_LDS, bool PRE, bool SEG = false, int MF = 0,
-          bool RSG = false, typename TIN = float, typename TOUT = float, int DLT = 0, bool HX = false>
+          bool RSG = false, typename TIN = float, typename TOUT = float, int DLT = 0>
 __global__ __launch_bounds__(MAXWAVES * 64, MINW) void stft_wave_kernel(const FastParams p) {
-  // HX: the exchange in two passes of N1/4 rows each, through half the LDS area (4.6 KB per wave at
-  // 32 x 16): with the row-segment walk's bin-major spectra (4.2 KB) that is all a wave needs, and five
-  // waves per SIMD fit where the 9.2 KB area allowed four (experiment: DESIGN.md section 4.1f).
   // DLT = K > 0: Deltas(K, context_window 2) of the features appended to every row by the same launch
   // (reference post.py:462-491; BASELINE.json configs[2]).  Work is dealt in RUNS: workgroup w takes
   // runs w, w + grid, ...; a run is run_len consecutive chunks of one utterance plus one halo chunk
@@ -329,22 +326,20 @@ __global__ __launch_bounds__(MAXWAVES * 64, MINW) void stft_wave_kernel(const Fa
   static_assert(MF == 0 || (N2 == 16 && N1 == 32 && MF == mfma_front_steps(NROWS)), "matrix-pipe front end: 32 x 16");
   static_assert(MF == 0 || 4 * MSLOTS * 64 <= G::EXCH_F2 * 2, "edge-frame gather reuses the exchange area");
   constexpr int NBP = (NB + 3) / 4 * 4;  // RSG: bins kept in LDS (bin NBP = dump slot), as build_rseg sizes them
-  constexpr int AREA = HX ? G::GROUPS * (COLS / 2) * RS * 2 : G::EXCH_F2 * 2;  // floats of LDS per wave
-  static_assert(!RSG || (G::GROUPS == 4 && ELL_LDS && !SEG && (NBP + 1) * 4 <= AREA),
+  static_assert(!RSG || (G::GROUPS == 4 && ELL_LDS && !SEG && (NBP + 1) * 4 <= G::EXCH_F2 * 2),
                 "row-segment walk: four frames per wave, tables in LDS");
-  static_assert(!HX || (RSG && MF == 0 && G::FULL && G::CPL == 1 && N2 == 16 && COLS == 16), "half exchange: 32 x 16, row segments");
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int g = lane / N2, r = lane % N2;
-  float *wbase = smem + wave * AREA;
-  float2 *exch = reinterpret_cast<float2 *>(wbase) + g * (HX ? COLS / 2 : COLS) * RS;
+  float *wbase = smem + wave * (G::EXCH_F2 * 2);
+  float2 *exch = reinterpret_cast<float2 *>(wbase) + g * COLS * RS;
   float *Pg = wbase + g * PSTR;
   // filter table -> LDS once per workgroup (read by every wave, every iteration): per-slot
   // weight rows.  Tables too large for LDS (dense complex banks) stay in global memory and
   // come through L1/L2.
   const int nthreads = p.waves * 64;
-  float2 *sw_lds = reinterpret_cast<float2 *>(smem + p.waves * AREA);  // [N2]
+  float2 *sw_lds = reinterpret_cast<float2 *>(smem + p.waves * (G::EXCH_F2 * 2));  // [N2]
   int *meta_lds = reinterpret_cast<int *>(sw_lds + N2);
   float *ellw_lds = reinterpret_cast<float *>(meta_lds + p.ell_meta_pad);
   if (threadIdx.x < N2) sw_lds[threadIdx.x] = p.tw_special[threadIdx.x];
@@ -354,7 +349,7 @@ __global__ __launch_bounds__(MAXWAVES * 64, MINW) void stft_wave_kernel(const Fa
   if constexpr (ELL_LDS)
     for (int i = threadIdx.x; i < p.ell_wfloats; i += nthreads) ellw_lds[i] = p.ell_w[i];
   // the wave areas start out zeroed so that never-written P padding is finite
-  for (int i = threadIdx.x; i < p.waves * AREA; i += nthreads) smem[i] = 0.0f;
+  for (int i = threadIdx.x; i < p.waves * G::EXCH_F2 * 2; i += nthreads) smem[i] = 0.0f;
   __syncthreads();
 
   // per-lane constants, loop invariant: window slice and inter-stage twiddles
@@ -713,17 +708,8 @@ __global__ __launch_bounds__(MAXWAVES * 64, MINW) void stft_wave_kernel(const Fa
         }
       } else {
         float *tmp = wbase;
-        constexpr int CHUNK = HX ? AREA / 64 : NROWS;  // rows the area holds at a time
 #pragma unroll 1
         for (int n1 = 0; n1 < NROWS; ++n1) {
-          if constexpr (HX) {
-            if (n1 == CHUNK) {  // first part back into registers, then the area again
-              wave_sync();
-#pragma unroll
-              for (int m = 0; m < CHUNK && m < NROWS; ++m) a[m] = tmp[m * 64 + lane];
-              wave_sync();
-            }
-          }
           const int idx = n1 * N2 + r;
           float v = 0.0f;
           if (idx < L) {
@@ -742,12 +728,11 @@ __global__ __launch_bounds__(MAXWAVES * 64, MINW) void stft_wave_kernel(const Fa
               v = (float)w;
             }
           }
-          tmp[(HX && n1 >= CHUNK ? n1 - CHUNK : n1) * 64 + lane] = v;
+          tmp[n1 * 64 + lane] = v;
         }
         wave_sync();
 #pragma unroll
-        for (int n1 = (HX && NROWS > CHUNK ? CHUNK : 0); n1 < NROWS; ++n1)
-          a[n1] = tmp[(HX && n1 >= CHUNK ? n1 - CHUNK : n1) * 64 + lane];
+        for (int n1 = 0; n1 < NROWS; ++n1) a[n1] = tmp[n1 * 64 + lane];
         wave_sync();
       }
       if (p.include_energy) {
@@ -804,14 +789,6 @@ __global__ __launch_bounds__(MAXWAVES * 64, MINW) void stft_wave_kernel(const Fa
         if constexpr (PDS_ABLATE & 4) {
           Ar[k1] = v.x;
           Ai[k1] = v.y;
-        } else if constexpr (HX) {
-          // (second pass below: the twiddled columns k1 >= COLS / 2 wait in their registers)
-          if (k1 < COLS / 2) {
-            exch[k1 * RS + r] = v;
-          } else {
-            Ar[k1] = v.x;
-            Ai[k1] = v.y;
-          }
         } else {
           exch[k1 * RS + r] = v;
         }
@@ -826,36 +803,8 @@ __global__ __launch_bounds__(MAXWAVES * 64, MINW) void stft_wave_kernel(const Fa
 #pragma unroll
     for (int q = 0; q < G::CPL; ++q) {
       const int kk = q * N2 + r;
-      const float4 *row = reinterpret_cast<const float4 *>(exch + (HX ? kk & (COLS / 2 - 1) : kk) * RS);
+      const float4 *row = reinterpret_cast<const float4 *>(exch + kk * RS);
       float zr[N2], zi[N2], Yr[N2], Yi[N2];
-      if constexpr (HX) {
-        // pass 1: lanes k1 < COLS / 2 take their rows; then the other half of the columns goes
-        // through the same rows (LDS operations of a wave execute in order)
-        if (kk < COLS / 2) {
-#pragma unroll
-          for (int j = 0; j < N2 / 2; ++j) {
-            const float4 v = row[j];
-            zr[2 * j] = v.x;
-            zi[2 * j] = v.y;
-            zr[2 * j + 1] = v.z;
-            zi[2 * j + 1] = v.w;
-          }
-        }
-        wave_sync();
-#pragma unroll
-        for (int k1 = COLS / 2; k1 <= NREG; ++k1) exch[(k1 - COLS / 2) * RS + r] = make_float2(Ar[k1], Ai[k1]);
-        wave_sync();
-        if (kk >= COLS / 2) {
-#pragma unroll
-          for (int j = 0; j < N2 / 2; ++j) {
-            const float4 v = row[j];
-            zr[2 * j] = v.x;
-            zi[2 * j] = v.y;
-            zr[2 * j + 1] = v.z;
-            zi[2 * j + 1] = v.w;
-          }
-        }
-      } else {
 #pragma unroll
       for (int j = 0; j < N2 / 2; ++j) {
         float4 v;
@@ -868,7 +817,6 @@ __global__ __launch_bounds__(MAXWAVES * 64, MINW) void stft_wave_kernel(const Fa
         zi[2 * j] = v.y;
         zr[2 * j + 1] = v.z;
         zi[2 * j + 1] = v.w;
-      }
       }
       if constexpr (PDS_ABLATE & 8) {
 #pragma unroll
@@ -1280,17 +1228,10 @@ constexpr bool fast_deltas_kind(int n) { return n == 512 || n == 1024; }
 
 bool fast_has_fused_deltas(const pds_stft_plan *plan) { return plan->fast.kind && fast_deltas_kind(plan->fast.kind); }
 
-// HXL: the five-waves-per-SIMD form of the 32 x 16 geometry (half exchange area, row-segment walk,
-// float32, no fused pre-emphasis); anything else the call needs takes the regular form
-template <int N1, int N2, int NROWS, int MINW, bool HXL = false>
+template <int N1, int N2, int NROWS, int MINW>
 static int32_t launch_wave(const pds_stft_plan *plan, const BatchArgs &a) {
   using G = WaveGeom<N1, N2, NROWS>;
-  if constexpr (HXL) {
-    if (a.preemph != 0.0 || a.in_f64 || a.dl_K > 0 || plan->fast.walk != 2 || plan->fast.rs_rounds == 0)
-      return launch_wave<N1, N2, NROWS, 4, false>(plan, a);
-  }
   constexpr int CU_WAVES = 4 * MINW;  // resident waves per CU that the register budget allows
-  constexpr int MAXW = CU_WAVES < 16 ? CU_WAVES : 16;  // waves per workgroup (1024 threads at most)
   const FastTables &ft = plan->fast;
   FastParams p;
   p.sig = a.d_signal;
@@ -1332,7 +1273,7 @@ static int32_t launch_wave(const pds_stft_plan *plan, const BatchArgs &a) {
   // LDS weights beat 8 waves reading them through L1/L2 by 33 %).  Tables too large even for that
   // stay in global memory.
   const size_t lds_cu = 160 * 1024;
-  const size_t per_wave = HXL ? (size_t)G::GROUPS * (G::COLS / 2) * G::RS * 8 : (size_t)G::EXCH_F2 * 8;
+  const size_t per_wave = (size_t)G::EXCH_F2 * 8;
   const int shapes[4][2] = {{CU_WAVES / 2, 2}, {CU_WAVES, 1}, {CU_WAVES * 3 / 4, 1}, {CU_WAVES * 5 / 8, 1}};
   int waves = CU_WAVES / 2, wgs_per_cu = 2;
   bool in_lds = false;
@@ -1354,7 +1295,7 @@ static int32_t launch_wave(const pds_stft_plan *plan, const BatchArgs &a) {
     // (segment sums live behind P in the wave's area)
     if (cand == 1 && (size_t)G::GROUPS * G::PSTR * 4 + (size_t)ft.seg_rounds * 64 * 16 > per_wave) continue;
     for (const auto &shape : shapes)
-      if (shape[0] <= MAXW && shape[0] * per_wave + fixed + table_bytes <= lds_cu / shape[1]) {
+      if (shape[0] * per_wave + fixed + table_bytes <= lds_cu / shape[1]) {
         waves = shape[0];
         wgs_per_cu = shape[1];
         in_lds = true;
@@ -1397,30 +1338,24 @@ static int32_t launch_wave(const pds_stft_plan *plan, const BatchArgs &a) {
   const size_t smem = waves * per_wave + fixed + (in_lds ? table_bytes : 0);
   constexpr bool W4 = G::GROUPS == 4;  // the walks over four frames exist for the 16-lane geometries
   const bool seg = W4 && walk == 1, rsg = W4 && walk == 2;
-  auto kern = pre      ? (rsg ? stft_wave_kernel<N1, N2, NROWS, MAXW, MINW, true, true, false, 0, W4>
-                              : stft_wave_kernel<N1, N2, NROWS, MAXW, MINW, true, true>)
-              : rsg    ? stft_wave_kernel<N1, N2, NROWS, MAXW, MINW, true, false, false, 0, W4>
-              : seg    ? stft_wave_kernel<N1, N2, NROWS, MAXW, MINW, true, false, W4>
-              : in_lds ? stft_wave_kernel<N1, N2, NROWS, MAXW, MINW, true, false>
-                       : stft_wave_kernel<N1, N2, NROWS, MAXW, MINW, false, false>;
-  int hx_which = -1;
-  if constexpr (HXL) {
-    if (!rsg || !in_lds) return launch_wave<N1, N2, NROWS, 4, false>(plan, a);
-    kern = stft_wave_kernel<N1, N2, NROWS, MAXW, MINW, true, false, false, 0, true, float, float, 0, true>;
-    hx_which = 0;
-  }
+  auto kern = pre      ? (rsg ? stft_wave_kernel<N1, N2, NROWS, CU_WAVES, MINW, true, true, false, 0, W4>
+                              : stft_wave_kernel<N1, N2, NROWS, CU_WAVES, MINW, true, true>)
+              : rsg    ? stft_wave_kernel<N1, N2, NROWS, CU_WAVES, MINW, true, false, false, 0, W4>
+              : seg    ? stft_wave_kernel<N1, N2, NROWS, CU_WAVES, MINW, true, false, W4>
+              : in_lds ? stft_wave_kernel<N1, N2, NROWS, CU_WAVES, MINW, true, false>
+                       : stft_wave_kernel<N1, N2, NROWS, CU_WAVES, MINW, false, false>;
   // matrix-pipe front end: the 32 x 16 geometry with LDS-resident filter tables, when the plan has
   // its tables for this row count
   constexpr int MFS = (N1 == 32 && N2 == 16) ? mfma_front_steps(NROWS) : 0;
   bool mf = false;
   if constexpr (MFS > 0) {
-    if (!HXL && in_lds && ft.d_mf_tab && ft.mf_rows == NROWS) {
+    if (in_lds && ft.d_mf_tab && ft.mf_rows == NROWS) {
       mf = true;
-      kern = pre   ? (rsg ? stft_wave_kernel<N1, N2, NROWS, MAXW, MINW, true, true, false, MFS, W4>
-                          : stft_wave_kernel<N1, N2, NROWS, MAXW, MINW, true, true, false, MFS>)
-             : rsg ? stft_wave_kernel<N1, N2, NROWS, MAXW, MINW, true, false, false, MFS, W4>
-             : seg ? stft_wave_kernel<N1, N2, NROWS, MAXW, MINW, true, false, W4, MFS>
-                   : stft_wave_kernel<N1, N2, NROWS, MAXW, MINW, true, false, false, MFS>;
+      kern = pre   ? (rsg ? stft_wave_kernel<N1, N2, NROWS, CU_WAVES, MINW, true, true, false, MFS, W4>
+                          : stft_wave_kernel<N1, N2, NROWS, CU_WAVES, MINW, true, true, false, MFS>)
+             : rsg ? stft_wave_kernel<N1, N2, NROWS, CU_WAVES, MINW, true, false, false, MFS, W4>
+             : seg ? stft_wave_kernel<N1, N2, NROWS, CU_WAVES, MINW, true, false, W4, MFS>
+                   : stft_wave_kernel<N1, N2, NROWS, CU_WAVES, MINW, true, false, false, MFS>;
     }
   }
   // float64 samples (pds_stft_batch_f64in): the common power-of-two geometries, LDS-resident tables,
@@ -1435,14 +1370,14 @@ static int32_t launch_wave(const pds_stft_plan *plan, const BatchArgs &a) {
       }
       mf = false;
       if (a.out_f64)
-        kern = rsg ? stft_wave_kernel<N1, N2, NROWS, MAXW, MINW, true, false, false, 0, W4, double, double>
-                   : stft_wave_kernel<N1, N2, NROWS, MAXW, MINW, true, false, false, 0, false, double, double>;
+        kern = rsg ? stft_wave_kernel<N1, N2, NROWS, CU_WAVES, MINW, true, false, false, 0, W4, double, double>
+                   : stft_wave_kernel<N1, N2, NROWS, CU_WAVES, MINW, true, false, false, 0, false, double, double>;
       else if (pre)
-        kern = rsg ? stft_wave_kernel<N1, N2, NROWS, MAXW, MINW, true, true, false, 0, W4, double, float>
-                   : stft_wave_kernel<N1, N2, NROWS, MAXW, MINW, true, true, false, 0, false, double, float>;
+        kern = rsg ? stft_wave_kernel<N1, N2, NROWS, CU_WAVES, MINW, true, true, false, 0, W4, double, float>
+                   : stft_wave_kernel<N1, N2, NROWS, CU_WAVES, MINW, true, true, false, 0, false, double, float>;
       else
-        kern = rsg ? stft_wave_kernel<N1, N2, NROWS, MAXW, MINW, true, false, false, 0, W4, double, float>
-                   : stft_wave_kernel<N1, N2, NROWS, MAXW, MINW, true, false, false, 0, false, double, float>;
+        kern = rsg ? stft_wave_kernel<N1, N2, NROWS, CU_WAVES, MINW, true, false, false, 0, W4, double, float>
+                   : stft_wave_kernel<N1, N2, NROWS, CU_WAVES, MINW, true, false, false, 0, false, double, float>;
       f64_which = 12 + (a.out_f64 ? 4 : pre ? 2 : 0) + (rsg ? 1 : 0);
     } else {
       set_error("stft_batch_f64in: no fused float64-input kernel for this transform size");
@@ -1461,10 +1396,10 @@ static int32_t launch_wave(const pds_stft_plan *plan, const BatchArgs &a) {
       }
       mf = false;
       kern = a.dl_K == 1
-                 ? (rsg ? stft_wave_kernel<N1, N2, NROWS, MAXW, MINW, true, false, false, 0, true, float, float, 1>
-                        : stft_wave_kernel<N1, N2, NROWS, MAXW, MINW, true, false, false, 0, false, float, float, 1>)
-                 : (rsg ? stft_wave_kernel<N1, N2, NROWS, MAXW, MINW, true, false, false, 0, true, float, float, 2>
-                        : stft_wave_kernel<N1, N2, NROWS, MAXW, MINW, true, false, false, 0, false, float, float, 2>);
+                 ? (rsg ? stft_wave_kernel<N1, N2, NROWS, CU_WAVES, MINW, true, false, false, 0, true, float, float, 1>
+                        : stft_wave_kernel<N1, N2, NROWS, CU_WAVES, MINW, true, false, false, 0, false, float, float, 1>)
+                 : (rsg ? stft_wave_kernel<N1, N2, NROWS, CU_WAVES, MINW, true, false, false, 0, true, float, float, 2>
+                        : stft_wave_kernel<N1, N2, NROWS, CU_WAVES, MINW, true, false, false, 0, false, float, float, 2>);
       dl_which = 18 + (a.dl_K - 1) * 2 + (rsg ? 1 : 0);
       for (int j = 0; j < 16; ++j) p.dl_taps[j] = a.dl_taps[j];
       p.dl_inner = plan->d.num_filts + (plan->d.include_energy ? 1 : 0);
@@ -1477,8 +1412,7 @@ static int32_t launch_wave(const pds_stft_plan *plan, const BatchArgs &a) {
   // (instantiation, device, variant) and remembered (relaxed atomics: a lost race repeats the call)
   constexpr int kDevices = 64;
   static std::atomic<size_t> attr_smem[kDevices][22];
-  const int which = hx_which >= 0    ? hx_which
-                    : dl_which >= 0  ? dl_which
+  const int which = dl_which >= 0    ? dl_which
                     : f64_which >= 0 ? f64_which
                                      : (pre ? (rsg ? 5 : 2) : rsg ? 4 : seg ? 3 : (in_lds ? 1 : 0)) + (mf ? 6 : 0);
   const bool cached = plan->device >= 0 && plan->device < kDevices;
@@ -1530,7 +1464,6 @@ static int32_t launch_wave(const pds_stft_plan *plan, const BatchArgs &a) {
 int32_t launch_stft_fast_f32(const pds_stft_plan *plan, const BatchArgs &a) {
   const int rows = plan->fast.rows;
 #ifdef PDS_DEV_ONLY512  // (ISA inspection builds: the headline instantiations alone)
-  if (plan->fast.kind == 512 && rows <= 25 && plan->fast.waves20) return launch_wave<32, 16, 25, 5, true>(plan, a);
   if (plan->fast.kind == 512 && rows <= 25) return launch_wave<32, 16, 25, 4>(plan, a);
   set_error("stft_batch: development build");
   return PDS_ERR_INVALID;
@@ -1544,9 +1477,6 @@ int32_t launch_stft_fast_f32(const pds_stft_plan *plan, const BatchArgs &a) {
       PDS_GEOM_ROWS(32, 8, 32, 4)
       break;
     case 512:
-      if (plan->fast.waves20) {  // (experiment, PDS_STFT_WAVES=20: five waves per SIMD)
-        if (rows <= 25) return launch_wave<32, 16, 25, 5, true>(plan, a);
-      }
       PDS_GEOM_ROWS(32, 16, 20, 4) PDS_GEOM_ROWS(32, 16, 25, 4) PDS_GEOM_ROWS(32, 16, 28, 4)
       PDS_GEOM_ROWS(32, 16, 30, 4) PDS_GEOM_ROWS(32, 16, 32, 4)
       break;
@@ -1788,8 +1718,6 @@ int32_t fast_tables_create(pds_stft_plan *plan, const double *window, const int3
     if (force && std::strcmp(force, "ell") == 0) ft.walk = 0;
     if (force && std::strcmp(force, "seg") == 0) ft.walk = ft.seg_rounds > 0 ? 1 : 0;
     if (force && std::strcmp(force, "rseg") == 0) ft.walk = ft.rs_rounds > 0 ? 2 : ft.walk;
-    const char *w20 = std::getenv("PDS_STFT_WAVES");
-    ft.waves20 = w20 && std::atoi(w20) == 20;
     if (std::getenv("PDS_DEBUG_PLAN"))
       std::fprintf(stderr,
                    "pds plan N=%d filters=%d: ell slots %d reads %ld | seg rounds %d len %d reads %ld | rseg rounds %d "
