@@ -66,6 +66,12 @@ WORKLOADS = {
          "use_power": True, "pad_to_nearest_power_of_two": False},
         160000, 1024, None,
     ),
+    # 8 kHz telephone speech, the usual 25 ms / 10 ms framing: L = 200 -> N = 256 (32 x 8, eight frames per wave)
+    "fbank40_8k_25_10_b1024x10s": (
+        {"name": "stft", "bank": {"name": "fbank", "num_filts": 40, "sampling_rate": 8000},
+         "frame_length_ms": 25, "frame_shift_ms": 10, "use_power": True},
+        80000, 1024, None,
+    ),
     # 48 kHz audio with the usual 25 ms / 10 ms framing: L = 1200 -> N = 2048 (64 x 32, two frames per wave)
     "fbank80_48k_25_10_b256x10s": (
         {"name": "stft", "bank": {"name": "fbank", "num_filts": 80, "sampling_rate": 48000},
