@@ -147,13 +147,13 @@ def compute_full_sharded(computer, signals: Sequence, gather: bool = True, group
     dev = torch.device("cuda", torch.cuda.current_device()) if on_gpu else torch.device("cpu")
     C = computer.num_coeffs
     packed = getattr(computer, "compute_packed", None)
-    if mine and on_gpu and packed is not None:
+    if mine and on_gpu and packed is not None and mine[0].dtype in (np.float32, np.float64):
         lengths = np.asarray([len(s) for s in mine], dtype=np.int64)
         offsets = np.concatenate([[0], np.cumsum(lengths)[:-1]]).astype(np.int64)
         flat = np.concatenate(mine) if lengths.sum() else np.zeros(0, mine[0].dtype)
         local, row_off = packed(torch.from_numpy(flat).to(dev), offsets, lengths)
         own_counts = np.diff(np.asarray(row_off, dtype=np.int64))
-    elif mine:  # (CPU groups in tests, computers without a packed interface)
+    elif mine:  # (CPU groups in tests, computers without a packed interface, integer samples)
         feats = computer.compute_full_batch(mine)
         own_counts = np.asarray([f.shape[0] for f in feats], dtype=np.int64)
         local = torch.from_numpy(np.ascontiguousarray(np.concatenate(feats))).to(dev)
