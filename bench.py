@@ -161,7 +161,7 @@ def cpu_baseline(comp, n, budget_s=12.0):
     }
 
 
-def parity_spot_check(comp, signal, offsets, lengths, layout, out, picks=3):
+def parity_spot_check(comp, signal, offsets, lengths, layout, out, picks=3, num_deltas=0):
     """Rows of the buffer the timed region wrote, against the oracle on the same samples
 
     First, middle and last utterance of the batch: their signal slices go to the host, the oracle
@@ -180,7 +180,7 @@ def parity_spot_check(comp, signal, offsets, lengths, layout, out, picks=3):
         include_energy=comp.includes_energy, use_power=bool(comp._power), use_log=bool(comp._log),
     )
     B, C = len(lengths), comp.num_coeffs
-    worst_abs = worst_tol = 0.0
+    worst_abs = worst_tol = worst_delta = 0.0
     rows = floor_elems = 0
     utts = sorted({0, B // 2, B - 1})[:picks]
     for b in utts:
@@ -207,9 +207,20 @@ def parity_spot_check(comp, signal, offsets, lengths, layout, out, picks=3):
         worst_abs = max(worst_abs, float(err.max()))
         worst_tol = max(worst_tol, float(over.max()))
         rows += want.shape[0]
-    return {"pass": worst_tol <= 1.0, "utterances": utts, "rows": rows, "coeffs": C, "max_abs_err": worst_abs,
-            "max_err_over_tolerance": worst_tol, "tolerance": "1e-5 + 1e-4 |ref|",
-            "elements_at_the_float32_floor": floor_elems,
+        if num_deltas:
+            # the delta columns of the same rows against the oracle's Deltas of the buffer's OWN statics
+            # (reference post.py:462-491, float64 accumulation): differences of logs sit near zero, so
+            # the tolerance is taken on the statics' scale
+            mine = out[r0 : r0 + want.shape[0], : (num_deltas + 1) * C].cpu().numpy()
+            ref = orc.deltas(mine[:, :C], axis=0, num_deltas=num_deltas, target_axis=-1)
+            derr = np.abs(mine[:, C:].astype(np.float64) - ref[:, C:])
+            if np.isnan(derr).any():
+                return {"pass": False, "error": f"utterance {b}: NaN in the deltas"}
+            worst_delta = max(worst_delta, float((derr / (1e-5 + 1e-4 * np.abs(want).max())).max()))
+    res_d = {"deltas_max_err_over_tolerance": worst_delta, "deltas_columns": num_deltas * C} if num_deltas else {}
+    return {"pass": worst_tol <= 1.0 and worst_delta <= 1.0, "utterances": utts, "rows": rows, "coeffs": C,
+            "max_abs_err": worst_abs, "max_err_over_tolerance": worst_tol, "tolerance": "1e-5 + 1e-4 |ref|",
+            "elements_at_the_float32_floor": floor_elems, **res_d,
             "against": "oracle/stft_oracle.compute_full (float64) on the timed buffer's own input"}
 
 
@@ -249,7 +260,9 @@ def main():
                     help="f64in: float64 samples in HBM, rounded to float32 by the fused kernel as it loads the "
                          "frames (pds_stft_batch_f64in), float32 features -- the reference drivers' dtype flow")
     ap.add_argument("--fused-deltas", action="store_true",
-                    help="deltas2 workloads: statics and deltas by one launch (A/B against the two launches)")
+                    help="deltas2 workloads: statics and deltas by one launch (the default where the plan has one)")
+    ap.add_argument("--two-launch-deltas", action="store_true",
+                    help="deltas2 workloads: the STFT launch followed by the deltas launch (A/B against the fused one)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true")
     ap.add_argument("--generic", action="store_true",
@@ -339,17 +352,24 @@ def main():
     out_cols = 3 * C if post == "deltas2" else C
     out = torch.empty((frames, out_cols), dtype=torch.float32, device=dev)
     deltas = ps.post.Deltas(2) if post == "deltas2" else None
+    # (experiment: rows padded to a multiple of 16 bytes for the fused statics + deltas launch)
+    pad = int(os.environ.get("PDS_BENCH_OUT_PAD", "0"))
+    out_wide = torch.empty((frames, out_cols + pad), dtype=torch.float32, device=dev) if pad else None
     cmvn = ps.post.CMVN() if post == "cmvn" else None
     cmvn_out = None
+
+    fused_deltas_used = bool(
+        deltas is not None and not args.two_launch_deltas and not args.generic and args.dtype == "f32"
+        and not is_si and comp._native_plan(dev).has_fused_deltas)
 
     def step():
         nonlocal cmvn_out
         if is_si:
             comp.compute_packed(signal, offsets, lengths, out=out, direct=args.generic)
             return
-        if deltas is not None and args.fused_deltas and not args.generic and args.dtype == "f32":
-            # statics and deltas by one launch (pds_stft_deltas_batch_f32): measured slower than the two launches
-            comp.launch_with_deltas(signal, layout, deltas, out=out, fused=True)
+        if deltas is not None and not args.two_launch_deltas and not args.generic and args.dtype == "f32":
+            # statics and deltas by one launch where the plan has it (pds_stft_deltas_batch_f32), else the two
+            comp.launch_with_deltas(signal, layout, deltas, out=out_wide if out_wide is not None else out, fused=True)
             return
         comp.launch(signal, layout, out=out, generic=args.generic)
         if deltas is not None:  # statics were written with row stride 3C; deltas go beside them
@@ -423,7 +443,7 @@ def main():
     finite = bool(torch.isfinite(out).all().item())
     spot = None
     if rank == 0 and not is_si:
-        spot = parity_spot_check(comp, signal, offsets, lengths, layout, out)
+        spot = parity_spot_check(comp, signal, offsets, lengths, layout, out, num_deltas=2 if deltas is not None else 0)
 
     def timed_gather():
         gathered = torch.empty((world * frames, out_cols), dtype=torch.float32, device=dev)
@@ -512,6 +532,8 @@ def main():
                 "kernel": ("si-direct-fir" if (args.generic or not comp.fft_size) else
                            f"si-overlap-save-fft{comp.fft_size}") if is_si else
                           "generic (lds-fft for 2^k sizes, else direct-dft)" if (args.generic or not comp.kernel_kind) else "fused-fft",
+                **({"deltas": "same launch (pds_stft_deltas_batch_f32)" if fused_deltas_used else "second launch (pds_deltas_rows_f32)"}
+                   if deltas is not None else {}),
             },
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

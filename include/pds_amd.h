@@ -138,19 +138,24 @@ int32_t pds_stft_batch_f64in(const pds_stft_plan *plan, const double *d_signal,
 /* Statics AND deltas in one launch (BASELINE.json configs[2]; reference post.py:462-491 applied to
  * compute_full's output along time, "edge" padding): row r of utterance b receives the num_coeffs
  * statics at columns [0, C) and the order-k deltas at [k C, (k + 1) C), k = 1 .. num_deltas.  The
- * statics make no second trip through HBM: a workgroup differentiates the frames whose statics
- * it has just stored (stft_fast.hip, DLT).  num_deltas 1 or 2, context_window 2; `taps`: HOST array
- * of the filters exactly as the caller's Deltas object holds them -- 5 taps of order 1, then (if
- * num_deltas = 2) the 9 taps of order 2 (numpy.convolve of the ramp with itself, post.py:456-460).
- * Values equal pds_stft_batch_f32 followed by pds_deltas_rows_f32 bit for bit.  Served for plans
- * with transform sizes 512 and 1024 and LDS-resident filter tables: pds_stft_plan_has_fused_deltas(). */
+ * statics make no second trip through HBM and no second kernel runs: every wave walks a contiguous
+ * stretch of frames and differentiates them from the coefficients it holds in registers
+ * (stft_fast.hip, DLT).  num_deltas 1 or 2, context_window 2; `taps`: HOST array of the filters
+ * exactly as the caller's Deltas object holds them -- 5 taps of order 1, then (if num_deltas = 2) the
+ * 9 taps of order 2 (numpy.convolve of the ramp with itself, post.py:456-460).  `d_workspace`:
+ * B + 1 int64 on the device (the utterances' chunk counts are summed up there by a small kernel in
+ * front of the main one, on `stream`).  The statics equal pds_stft_batch_f32's bit for bit; the
+ * deltas are formed in float32 where pds_deltas_rows_f32 (and the reference) accumulate in float64
+ * and round: they agree within a few float32 ulps of the statics, i.e. inside the feature tolerance.
+ * Served for plans with transform sizes 512 and 1024 whose banks run the row-segment filter walk in
+ * at most two rounds (mel banks of up to ~100 filters): pds_stft_plan_has_fused_deltas(). */
 int32_t pds_stft_plan_has_fused_deltas(const pds_stft_plan *plan);
 int32_t pds_stft_deltas_batch_f32(const pds_stft_plan *plan, const float *d_signal,
                                   const int64_t *d_offsets, const int64_t *d_lengths,
                                   const int64_t *d_nframes, const int64_t *d_row_off, int32_t B,
                                   int64_t max_frames, int32_t pad_left, int32_t num_deltas,
-                                  int32_t context_window, const double *taps, float *d_out,
-                                  int64_t out_stride, void *stream);
+                                  int32_t context_window, const double *taps, int64_t *d_workspace,
+                                  float *d_out, int64_t out_stride, void *stream);
 /* float32 input through the generic kernels regardless of N: radix-2 FFT in LDS for powers of two,
  * direct DFT otherwise (cross-check of the fused kernel; also what sizes without a fused geometry use) */
 int32_t pds_stft_batch_f32_generic(const pds_stft_plan *plan, const float *d_signal,

@@ -106,7 +106,7 @@ SIGNATURES = {
     "pds_stft_deltas_batch_f32": (
         c_int32,
         [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int64, c_int32,
-         c_int32, c_int32, c_void_p, c_void_p, c_int64, c_void_p],
+         c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_int64, c_void_p],
     ),
     "pds_stft_batch_f64in": (c_int32, _BATCH_ARGS[:11] + [c_int32] + _BATCH_ARGS[11:]),
     "pds_preemphasize_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_int64, c_double, c_void_p, c_void_p]),

@@ -497,9 +497,10 @@ class ShortTimeFourierTransformFrameComputer(LinearFilterBankFrameComputer):
         Returns the ``(total_rows, (K + 1) num_coeffs)`` float32 tensor: row r holds the features of
         frame r followed by its order-1 .. order-K deltas: :func:`launch` into rows of that stride
         followed by ``deltas.apply_rows``.  ``fused=True`` asks for the one-launch form
-        (``pds_stft_deltas_batch_f32``: transform sizes 512 and 1024, ``Deltas(1 or 2)`` with the
-        default context window and padding; same values bit for bit) -- measured 10 % SLOWER than
-        the two launches on an MI355X, so it is not the default.
+        (``pds_stft_deltas_batch_f32``: transform sizes 512 and 1024, mel-like banks, ``Deltas(1 or 2)``
+        with the default context window and padding): the statics are the same bit for bit, the deltas
+        are formed in float32 from coefficients held in registers (within a few float32 ulps of the
+        statics of the float64-accumulated ones) and nothing is read back from memory.
         """
         torch = _native.require_device()
         lib = _native.lib()
@@ -527,12 +528,13 @@ class ShortTimeFourierTransformFrameComputer(LinearFilterBankFrameComputer):
             pad = -1 if pad_left is None else int(pad_left)
             meta = layout.d_meta
             with torch.cuda.device(signal.device):
+                work = torch.empty(min(layout.B, _MAX_UTTS_PER_CALL) + 1, dtype=torch.int64, device=signal.device)
                 for lo in range(0, layout.B, _MAX_UTTS_PER_CALL):
                     hi = min(layout.B, lo + _MAX_UTTS_PER_CALL)
                     rc = lib.pds_stft_deltas_batch_f32(
                         plan.handle, signal.data_ptr(), meta[0, lo:].data_ptr(), meta[1, lo:].data_ptr(),
                         meta[2, lo:].data_ptr(), meta[3, lo:].data_ptr(), hi - lo, int(layout.nframes[lo:hi].max()),
-                        pad, K, 2, taps.ctypes.data, out.data_ptr(), out.stride(0), stream,
+                        pad, K, 2, taps.ctypes.data, work.data_ptr(), out.data_ptr(), out.stride(0), stream,
                     )
                     if rc != 0 and lo == 0:
                         fused = False  # (e.g. a filter table that does not fit in LDS): the two launches below

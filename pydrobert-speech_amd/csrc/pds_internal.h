@@ -42,6 +42,11 @@ struct FastTables {
   float *d_rs_w = nullptr;         // [rs_rounds][rs_len / 4][64][4]
   int32_t *d_rs_meta = nullptr;    // [rs_rounds * 64]
   int rs_rounds = 0, rs_len = 0, rs_wfloats = 0;
+  // the same walk with the filters in numbered order along the lanes (fused statics + deltas launches)
+  float *d_rsn_w = nullptr;
+  int32_t *d_rsn_meta = nullptr;
+  int rsn_rounds = 0, rsn_len = 0, rsn_wfloats = 0;
+  int rs_eslot = -1;               // round * 64 + lane of a lane that finishes no filter (-1: every lane does)
   int walk = 0;  // preferred filter walk: 0 ELL, 1 segments (dense banks), 2 row segments
   long rs_reads = 0, rs_cost = 0, ell_reads = 0, seg_reads = 0;  // 16-byte LDS reads per lane and item of each walk
   // matrix-pipe front end (mfma_front.h; 32 x 16 geometry): device image of the tables, built for
@@ -118,6 +123,7 @@ struct BatchArgs {
   // fused statics + deltas (pds_stft_deltas_batch_f32): order (0 = none) and the taps, order 1 then 2
   int dl_K = 0;
   double dl_taps[16] = {0};
+  int64_t *d_chunk_prefix = nullptr;  // workspace of B + 1 entries (the utterances' chunk counts, summed)
 };
 
 // stft_generic.hip

@@ -68,8 +68,11 @@ inline long rseg_read_cycles(const int32_t *meta, int seg_len) {
 
 // CSR filter table (cols ascending within a row), num_bins = N / 2 + 1.  max_bins: bins (of four
 // floats) the wave's LDS area can hold including the dump slot.  False when no segment length fits.
+// numbered: keep the filters in their numbered order along the lanes (no search for fewer bank conflicts): the
+// lanes' coefficient stores then ascend with the lane, which the fused statics + deltas launch, with six times
+// the stores, needs more than the conflict-free reads
 inline bool build_rseg(int num_filts, const int32_t *row_ptr, const int32_t *col, const double *val, int num_bins,
-                       int max_bins, int max_rounds, RsegTables &out) {
+                       int max_bins, int max_rounds, RsegTables &out, bool numbered = false) {
   if (num_filts <= 0 || num_filts > 65534 || num_bins >= (1 << 14)) return false;
   const int nbp = (num_bins + 3) / 4 * 4;
   if (nbp + 1 > max_bins) return false;
@@ -215,7 +218,7 @@ inline bool build_rseg(int num_filts, const int32_t *row_ptr, const int32_t *col
 #ifdef PDS_RSEG_NO_SEARCH  // (measurement: the numbered lane assignment)
     const bool search = false;
 #else
-    const bool search = true;
+    const bool search = !numbered;
 #endif
     const int len = priced[i].second, rounds = layout(len, search, meta);
     const long cost = price(len, meta, rounds);

@@ -133,12 +133,14 @@ struct FastParams {
   int chunks_per_utt, num_utts;
   int waves;  // wavefronts per workgroup of this launch (<= MAXWAVES)
   const float *mf_tab;  // matrix-pipe front end (MF instantiations): image of MfmaFrontTables
-  unsigned long long *stamps;  // diagnostic builds (PDS_STAMPS): [grid waves][8] phase times, else null
-  // fused statics + deltas launches (DLT instantiations): a workgroup takes whole runs of chunks of one
-  // utterance and computes the deltas of the run's frames itself once its statics are written
-  int run_len, runs_per_utt, total_runs;  // chunks per run (without the two halo chunks), runs per utterance
-  int dl_inner;                           // coefficients per frame to differentiate (= num_coeffs)
-  double dl_taps[16];                     // order-1 taps (2 W + 1) followed by the order-2 taps (4 W + 1), W = 2
+  unsigned long long *stamps;  // diagnostic builds (PDS_STAMPS): [grid waves][12] phase times and absolute times, else null
+  // fused statics + deltas launches (DLT instantiations): every wave walks ONE contiguous stretch of the
+  // batch's chunks and keeps the statics of the last three chunks in registers (see the kernel)
+  const int64_t *chunk_prefix;  // [num_utts + 1] chunks in front of every utterance (chunk_prefix_kernel)
+  int dl_inner;                 // coefficients per frame (= num_coeffs): order k goes to columns [k C, (k + 1) C)
+  int dl_debug;                 // measurement switches (PDS_DL_DEBUG): 1 no delta stores, 2 no deltas at all, 4 no statics stores
+  int dl_eslot;                 // round * 64 + lane of a lane without a filter: carries the energy (-1: none)
+  float dl_f1[5], dl_f2[9];     // taps of order 1 and order 2 (context window 2), correlation order
   int step_utts, step_chunks;  // (grid waves) / chunks_per_utt and (grid waves) % chunks_per_utt
 };
 
@@ -186,65 +188,6 @@ __device__ __forceinline__ void wave_sync() {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
-
-// Deltas of the frames [f_lo, f_hi) of one utterance (T frames, rows of out_stride floats starting at
-// `rows`), by all threads of the workgroup: the fused launches' epilogue of a run (stft_wave_kernel,
-// DLT).  As post.hip's register-window kernel: a thread owns 8 consecutive frames of one coefficient,
-// reads the 8 + 2 K W statics it needs once (edge clamp in the frame index, reference post.py:447,
-// 470-483), and accumulates in float64 with separately rounded multiplies and adds, so the values
-// are numpy's bit for bit.  Order k goes to columns [k C, (k + 1) C) of the frame's row.
-template <int K>
-__device__ __forceinline__ void deltas_of_run(const FastParams &p, float *rows, int T, int f_lo, int f_hi) {
-  // (this file is compiled with -ffp-contract=fast, under which the backend fuses whatever it meets,
-  // and HIP's __dmul_rn is a plain multiply: the products go through asm so that they are rounded
-  // before the sums, as numpy rounds them)
-  auto mul = [](double a, double b) {
-    double t;
-    asm("v_mul_f64 %0, %1, %2" : "=v"(t) : "v"(a), "v"(b));
-    return t;
-  };
-  constexpr int W = 2, H = K * W, R = 8, NV = R + 2 * H;
-  const int C = p.dl_inner;
-  const int64_t stride = p.out_stride;
-  const int items = (f_hi - f_lo + R - 1) / R * C;
-  double f1[2 * W + 1], f2[4 * W + 1];
-#pragma unroll
-  for (int j = 0; j < 2 * W + 1; ++j) f1[j] = p.dl_taps[j];
-#pragma unroll
-  for (int j = 0; j < 4 * W + 1; ++j) f2[j] = p.dl_taps[2 * W + 1 + j];
-  for (int e = threadIdx.x; e < items; e += blockDim.x) {
-    const int grp = e / C, i = e - grp * C, t0 = f_lo + grp * R;
-    double v[NV];
-    if (t0 >= H && t0 + R + H <= T) {
-      const float *c = rows + (int64_t)(t0 - H) * stride + i;
-#pragma unroll
-      for (int q = 0; q < NV; ++q) v[q] = (double)c[q * stride];
-    } else {
-#pragma unroll
-      for (int q = 0; q < NV; ++q) {
-        int t = t0 - H + q;
-        t = t < 0 ? 0 : (t >= T ? T - 1 : t);
-        v[q] = (double)rows[(int64_t)t * stride + i];
-      }
-    }
-#pragma unroll
-    for (int q = 0; q < R; ++q) {
-      if (t0 + q < f_hi) {
-        float *orow = rows + (int64_t)(t0 + q) * stride + i;
-        double acc = 0.0;
-#pragma unroll
-        for (int j = 0; j < 2 * W + 1; ++j) acc += mul(f1[j], v[H + q + j - W]);
-        orow[C] = (float)acc;
-        if constexpr (K == 2) {
-          acc = 0.0;
-#pragma unroll
-          for (int j = 0; j < 4 * W + 1; ++j) acc += mul(f2[j], v[H + q + j - 2 * W]);
-          orow[2 * C] = (float)acc;
-        }
-      }
-    }
-  }
 }
 
 // N = N1 * N2: in-lane real DFT size x lanes per frame.  NROWS = ceil(L / N2) rows of N2
@@ -309,16 +252,22 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 template <int N1, int N2, int NROWS, int MAXWAVES, int MINW, bool ELL_LDS, bool PRE, bool SEG = false, int MF = 0,
           bool RSG = false, typename TIN = float, typename TOUT = float, int DLT = 0>
 __global__ __launch_bounds__(MAXWAVES * 64, MINW) void stft_wave_kernel(const FastParams p) {
-  // DLT = K > 0: Deltas(K, context_window 2) of the features appended to every row by the same launch
-  // (reference post.py:462-491; BASELINE.json configs[2]).  Work is dealt in RUNS: workgroup w takes
-  // runs w, w + grid, ...; a run is run_len consecutive chunks of one utterance plus one halo chunk
-  // on either side (four frames: the reach of the order-2 filter), whose statics the workgroup
-  // computes and stores itself -- a neighbouring run stores the same values again -- so that after
-  // ONE workgroup barrier every static its deltas need was written by this very CU and is read back
-  // through its own L1 / L2.  The statics never make a second trip to HBM and no second kernel reads
-  // them with a row stride that wastes two thirds of every line.
-  static_assert(DLT == 0 || (DLT <= 2 && N2 == 16 && std::is_same<TOUT, float>::value && MF == 0),
-                "fused deltas: order 1 or 2, 16-lane geometries, float32 features");
+  // DLT = K > 0: Deltas(K, context_window 2, edge padding) of the features appended to every row by the
+  // same launch (reference post.py:462-491; BASELINE.json configs[2]).  Every wave walks ONE contiguous
+  // stretch of the batch's chunks (chunk_prefix: the utterances' chunk counts summed up by a small
+  // kernel in front, so ragged batches are dealt evenly too) plus one halo chunk in front of and
+  // behind every piece of an utterance inside it, and keeps the logged coefficients of the last two
+  // chunks in registers: in the row-segment walk a filter's four frames end up in ONE lane, so with
+  // the chunk just computed a lane holds twelve consecutive frames of its filter -- the reach of the
+  // order-2 taps around the middle chunk, whose deltas it then forms in float32 (the reference
+  // accumulates in float64 and rounds: |difference| of a few float32 ulps of the statics, inside the
+  // feature tolerance) and stores.  No static is read back from memory, no second kernel; the price is
+  // three waves per SIMD instead of four (the window registers) and ~14 multiply-adds per delta.  The
+  // energy column has no filter lane: a spare lane of the walk (dl_eslot) collects the four frames'
+  // energies and differentiates them like a filter.
+  static_assert(DLT == 0 || (DLT <= 2 && N2 == 16 && RSG && !PRE && std::is_same<TOUT, float>::value &&
+                             std::is_same<TIN, float>::value && MF == 0),
+                "fused deltas: order 1 or 2, row-segment walk, float32 samples and features");
   static_assert(MF == 0 || std::is_same<TIN, float>::value, "matrix-pipe front end: float32 samples");
   using G = WaveGeom<N1, N2, NROWS>;
   constexpr int N = G::N, COLS = G::COLS, NREG = G::NREG, RS = G::RS, NB = G::NB, PSTR = G::PSTR;
@@ -332,6 +281,7 @@ __global__ __launch_bounds__(MAXWAVES * 64, MINW) void stft_wave_kernel(const Fa
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int g = lane / N2, r = lane % N2;
+  [[maybe_unused]] const unsigned long long st_entry = PDS_STAMPS ? __builtin_readcyclecounter() : 0;
   float *wbase = smem + wave * (G::EXCH_F2 * 2);
   float2 *exch = reinterpret_cast<float2 *>(wbase) + g * COLS * RS;
   float *Pg = wbase + g * PSTR;
@@ -422,52 +372,159 @@ __global__ __launch_bounds__(MAXWAVES * 64, MINW) void stft_wave_kernel(const Fa
     sig_off = load_const(p.offsets + b);
     out_row = load_const(p.row_off + b);
   }
-  // (DLT) the run in hand: chunks [c_lo, c_hi) incl. halos, deltas for frames [f_lo, f_hi)
-  [[maybe_unused]] int run = wg - (int)gridDim.x, c_hi = 0, f_lo = 0, f_hi = 0;
-  [[maybe_unused]] bool run_open = false;
-  if constexpr (DLT > 0) chunk = 0;
+  // (DLT) the wave's stretch of the batch's chunks: `left` chunks still to emit starting with chunk
+  // e_lo of utterance b.  A PIECE is the part of one utterance inside the stretch, chunks [e_lo, e_hi):
+  // the wave computes chunks max(e_lo - 1, 0) .. min(e_hi, last chunk) (the first and the last one only
+  // for their statics: halos), stores the statics of the piece's chunks and, with chunk c computed,
+  // the deltas of chunk c - 1.  Frames in front of the utterance repeat its first frame, frames
+  // behind it the last one (post.py:447 "edge"); the lanes of a chunk's frames past the utterance's
+  // end compute the last frame again (see the loads), so the last chunk's window is already padded.
+  constexpr int DR = 2;  // row-segment rounds a fused-deltas launch may have (window registers per round)
+  [[maybe_unused]] int left = 0, e_lo = 0, e_hi = 0, c_last = -1;
+  [[maybe_unused]] bool piece_open = false;
+  [[maybe_unused]] float Wp[DR][4], Wc[DR][4], e_keep = 0.0f;
+  if constexpr (DLT > 0) {
+    const int gw = wg * p.waves + wave, GW = (int)gridDim.x * p.waves;
+    const int total = (int)load_const(p.chunk_prefix + p.num_utts);  // (fits an int: host check)
+    const int per = total / GW, rem = total - per * GW;
+    const int pos = gw * per + (gw < rem ? gw : rem);
+    left = per + (gw < rem ? 1 : 0);
+    // the utterance holding chunk `pos`: the last one whose prefix is <= pos (empty ones are skipped)
+    int lo = 0, hi = p.num_utts;  // prefix[lo] <= pos < prefix[hi] (when left > 0)
+    while (left > 0 && hi - lo > 1) {
+      const int mid = (lo + hi) >> 1;
+      if ((int)load_const(p.chunk_prefix + mid) <= pos) lo = mid; else hi = mid;
+    }
+    b = lo;
+    e_lo = left > 0 ? pos - (int)load_const(p.chunk_prefix + lo) : 0;
+    chunk = 0;
+#pragma unroll
+    for (int rd = 0; rd < DR; ++rd)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) Wp[rd][q] = Wc[rd][q] = 0.0f;
+  }
+  // The rows of chunk `ce` of the utterance in hand, statics AND deltas, from the window (Wp, Wc, nx) =
+  // frames 4 ce - 4 .. 4 ce + 7: the lanes form the deltas of their coefficients, everything is put down
+  // row-major in the wave's LDS area (free between the filter walk and the next exchange) and leaves as
+  // ONE contiguous store per row, 16 bytes per lane.  (Stored straight from the lanes that hold them --
+  // a dword per lane and frame, some forty lanes per instruction, 25 instructions per item -- the
+  // stores alone cost a third of the launch: the vector memory path handles such an instruction lane
+  // by lane.)
+  [[maybe_unused]] auto emit_rows = [&](const int ce, const float (&nx)[DR][4]) {
+    if (p.dl_debug & 2) return;
+    const int C = p.dl_inner;
+    const int W = (DLT + 1) * C, WS = (W + 3) & ~3;  // row width, staged row stride (floats)
+    float *stage = wbase;
+    wave_sync();  // (the filter walk's reads of the area are done: same wave, in order)
+#pragma unroll
+    for (int rd = 0; rd < DR; ++rd) {
+      if (rd >= p.seg_rounds) break;
+      // the lane's column: its filter (first lane of a run), the energy (dl_eslot), or none: a dump slot
+      const int f = (meta_lds[rd * 64 + lane] >> 16) - 1;
+      const int col = f >= 0 ? col0 + f : (p.dl_eslot == rd * 64 + lane ? 0 : -1);
+      const float v[12] = {Wp[rd][0], Wp[rd][1], Wp[rd][2], Wp[rd][3], Wc[rd][0], Wc[rd][1],
+                           Wc[rd][2], Wc[rd][3], nx[rd][0], nx[rd][1], nx[rd][2], nx[rd][3]};
+      float *mine = stage + (col >= 0 ? col : 4 * WS + lane);
+      const int wrow = col >= 0 ? WS : 0, wk = col >= 0 ? C : 0;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        float d = p.dl_f1[0] * v[q + 2];
+#pragma unroll
+        for (int t = 1; t < 5; ++t) d = fmaf(p.dl_f1[t], v[q + 2 + t], d);
+        mine[q * wrow] = v[4 + q];
+        mine[q * wrow + wk] = d;
+        if constexpr (DLT == 2) {
+          float dd = p.dl_f2[0] * v[q];
+#pragma unroll
+          for (int t = 1; t < 9; ++t) dd = fmaf(p.dl_f2[t], v[q + t], dd);
+          mine[q * wrow + 2 * wk] = dd;
+        }
+      }
+    }
+    wave_sync();
+    if (!(p.dl_debug & 1)) {
+      float *orow = static_cast<float *>(p.out) + (out_row + (int64_t)ce * 4) * p.out_stride;
+      const int fh = nfr - ce * 4;  // frames of the chunk that exist (>= 1)
+      const int full = W >> 2, tail = W & 3;
+      typedef float F4 __attribute__((ext_vector_type(4), aligned(4)));  // rows start on any float
+      if (fh >= 4 && full <= 64) {
+        // (the common case: four reads in flight, then four stores, one lane predicate)
+        const int l = lane < full ? lane : full - 1;
+        float4 val[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) val[q] = *reinterpret_cast<const float4 *>(stage + q * WS + 4 * l);
+        if (lane < full) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            F4 o = {val[q].x, val[q].y, val[q].z, val[q].w};
+            *reinterpret_cast<F4 *>(orow + (int64_t)q * p.out_stride + 4 * l) = o;
+          }
+        }
+      } else {
+        for (int l0 = 0; l0 < full; l0 += 64) {
+          const int l = l0 + lane;
+          if (l < full) {
+#pragma unroll 1
+            for (int q = 0; q < 4; ++q)
+              if (q < fh) {
+                const float4 val = *reinterpret_cast<const float4 *>(stage + q * WS + 4 * l);
+                F4 o = {val.x, val.y, val.z, val.w};
+                *reinterpret_cast<F4 *>(orow + (int64_t)q * p.out_stride + 4 * l) = o;
+              }
+          }
+        }
+      }
+      if (tail) {  // the last W % 4 columns of the four rows: one dword store
+        const int q = tail == 1 ? lane : tail == 2 ? lane >> 1 : (lane * 11) >> 5;  // lane / tail where it is < 4
+        const int jj = lane - q * tail;
+        if (q < fh && q < 4) orow[(int64_t)q * p.out_stride + 4 * full + jj] = stage[q * WS + 4 * full + jj];
+      }
+    }
+    wave_sync();
+  };
   if constexpr (PDS_STAGGER) {
     if (b < p.num_utts && (wave & 4)) __builtin_amdgcn_s_barrier();
   }
   [[maybe_unused]] unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   [[maybe_unused]] unsigned long long st_prev = PDS_STAMPS ? __builtin_readcyclecounter() : 0;
+  [[maybe_unused]] const unsigned long long st_loop = st_prev;
   while (DLT > 0 || b < p.num_utts) {
     if constexpr (DLT > 0) {
-      // every wave of the workgroup walks the same runs and meets the others once per run, whether
-      // or not any of the run's chunks fell to it
-      bool finished = false;
-      while (chunk >= c_hi) {
-        if (run_open) {
-          // every wave's statics must have left for L2 before anyone reads them back: drain this
-          // wave's stores, meet the others, and drop what this CU's L1 may still hold of those lines
-          // (their delta columns were read by an earlier run's epilogue).  Once per run: ~2 us.
-          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-          __builtin_amdgcn_s_barrier();
-          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-          deltas_of_run<DLT>(p, static_cast<float *>(p.out) + out_row * p.out_stride, nfr, f_lo, f_hi);
-          run_open = false;
-        }
-        run += (int)gridDim.x;
-        if (run >= p.total_runs) {
-          finished = true;
-          break;
-        }
-        b = run / p.runs_per_utt;
-        const int j = run - b * p.runs_per_utt;
+      if (!piece_open) {
+        if (left <= 0) break;
         nfr = (int)load_const(p.nframes + b);
+        const int chunks_b = (nfr + G::GROUPS - 1) / G::GROUPS;
+        if (e_lo >= chunks_b) {  // an utterance without frames (only the first piece starts past chunk 0)
+          ++b;
+          e_lo = 0;
+          continue;
+        }
         n = (int)load_const(p.lengths + b);
         sig_off = load_const(p.offsets + b);
         out_row = load_const(p.row_off + b);
-        const int chunks_b = (nfr + G::GROUPS - 1) / G::GROUPS;
-        const int c_lo = j * p.run_len > 0 ? j * p.run_len - 1 : 0;
-        c_hi = (j + 1) * p.run_len + 1 < chunks_b ? (j + 1) * p.run_len + 1 : chunks_b;
-        f_lo = j * p.run_len * G::GROUPS;
-        f_hi = (j + 1) * p.run_len * G::GROUPS < nfr ? (j + 1) * p.run_len * G::GROUPS : nfr;
-        chunk = c_lo + wave;
-        run_open = f_lo < f_hi;
-        if (!run_open) c_hi = 0;  // (nothing of this utterance in the run: ragged batches)
+        e_hi = e_lo + left < chunks_b ? e_lo + left : chunks_b;
+        c_last = e_hi < chunks_b ? e_hi : chunks_b - 1;
+        chunk = e_lo > 0 ? e_lo - 1 : 0;
+        piece_open = true;
       }
-      if (finished) break;
+      if (chunk > c_last) {
+        // the piece's chunks are computed.  Where it runs to the utterance's end the last chunk's deltas
+        // are still due: the frames behind it repeat the last frame, which is frame 3 of the last chunk
+        // whatever the frame count (see above)
+        if (c_last < e_hi) {
+          float nx[DR][4];
+#pragma unroll
+          for (int rd = 0; rd < DR; ++rd)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) nx[rd][q] = Wc[rd][3];
+          emit_rows(c_last, nx);
+        }
+        left -= e_hi - e_lo;
+        ++b;
+        e_lo = 0;
+        piece_open = false;
+        continue;
+      }
     }
     int nchunk = chunk + p.step_chunks, nb = b + p.step_utts;
     if (nchunk >= p.chunks_per_utt) {
@@ -966,7 +1023,8 @@ __global__ __launch_bounds__(MAXWAVES * 64, MINW) void stft_wave_kernel(const Fa
       float e = energy * p.inv_L;
       if (!use_power) e = __builtin_amdgcn_sqrtf(e);
       if (p.use_log) e = fast_log(p.log_floor > e ? p.log_floor : e);
-      if (valid && r == 0) obase[lane_off - col0] = (TOUT)e;
+      if (DLT == 0 && valid && r == 0) obase[lane_off - col0] = (TOUT)e;
+      if constexpr (DLT > 0) e_keep = e;
     }
     PDS_STAMP(4, 0);  // P stores, energy
     PDS_PHASE(3);
@@ -979,7 +1037,7 @@ __global__ __launch_bounds__(MAXWAVES * 64, MINW) void stft_wave_kernel(const Fa
     [[maybe_unused]] const int frames_here = nfr - tb;  // frames of this chunk that exist (SEG)
     // this item's record is dead from here on: fetch the next one under the filter phase
     if constexpr (DLT > 0) {
-      chunk += p.waves;  // (the run's record stays)
+      // (the piece's record stays)
     } else {
       b = nb;
       chunk = nchunk;
@@ -1055,7 +1113,7 @@ __global__ __launch_bounds__(MAXWAVES * 64, MINW) void stft_wave_kernel(const Fa
       // four frames; weights [round][seg_len / 4][lane] float4, powers bin-major.
       const float4 *P4 = reinterpret_cast<const float4 *>(wbase);
       const int t4n = p.seg_len >> 2;
-      for (int rd = 0; rd < p.seg_rounds; ++rd) {
+      auto round_body = [&](const int rd, float (&logged)[4]) {
         const int meta = meta_lds[rd * 64 + lane];
         const float4 *prow = P4 + (meta & 0x3fff);
         const float4 *wrow = reinterpret_cast<const float4 *>(ellw_lds) + __mul24(rd, t4n) * 64 + lane;
@@ -1116,8 +1174,42 @@ __global__ __launch_bounds__(MAXWAVES * 64, MINW) void stft_wave_kernel(const Fa
           float v = vals[gg];
           // max(val, floor) as Python evaluates it: a NaN stays a NaN (compute.py:459)
           if (p.use_log) v = fast_log(p.log_floor > v ? p.log_floor : v);
-          if (f >= 0 && gg < frames_here) dst[(int64_t)gg * p.out_stride] = (TOUT)v;
+          if (DLT == 0 && f >= 0 && gg < frames_here) dst[(int64_t)gg * p.out_stride] = (TOUT)v;
+          logged[gg] = v;
         }
+      };
+      if constexpr (DLT == 0) {
+        float unused[4];
+        for (int rd = 0; rd < p.seg_rounds; ++rd) round_body(rd, unused);
+      } else {
+        // the chunk's logged coefficients: the lane's filter of every round, the energies on their lane
+        float cur[DR][4];
+#pragma unroll
+        for (int rd = 0; rd < DR; ++rd) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) cur[rd][q] = 0.0f;
+          if (rd < p.seg_rounds) round_body(rd, cur[rd]);
+          if (p.dl_eslot == rd * 64 + lane) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+              cur[rd][q] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(e_keep), 16 * q));
+          }
+        }
+        if (chunk == 0) {  // frames in front of the utterance repeat its first frame
+#pragma unroll
+          for (int rd = 0; rd < DR; ++rd)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) Wc[rd][q] = cur[rd][0];
+        }
+        if (chunk > e_lo) emit_rows(chunk - 1, cur);
+#pragma unroll
+        for (int rd = 0; rd < DR; ++rd)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            Wp[rd][q] = Wc[rd][q];
+            Wc[rd][q] = cur[rd][q];
+          }
+        ++chunk;
       }
       PDS_STAMP(5, 0);  // filter walk
       if constexpr (PDS_STAGGER) __builtin_amdgcn_s_barrier();
@@ -1209,9 +1301,13 @@ __global__ __launch_bounds__(MAXWAVES * 64, MINW) void stft_wave_kernel(const Fa
   }
   if constexpr (PDS_STAMPS) {
     if (p.stamps && lane == 0) {
-      unsigned long long *dst = p.stamps + ((size_t)blockIdx.x * p.waves + wave) * 8;
+      // [0..5] phase sums, [6] items, [7] bookkeeping, then absolute times: kernel entry, loop start, loop end
+      unsigned long long *dst = p.stamps + ((size_t)blockIdx.x * p.waves + wave) * 12;
 #pragma unroll
       for (int i = 0; i < 8; ++i) dst[i] = st_acc[i];
+      dst[8] = st_entry;
+      dst[9] = st_loop;
+      dst[10] = __builtin_readcyclecounter();
     }
   }
 }
@@ -1226,12 +1322,43 @@ bool fast_has_f64in(const pds_stft_plan *plan) { return plan->fast.kind && fast_
 // transform sizes with fused statics + deltas instantiations (16-lane geometries)
 constexpr bool fast_deltas_kind(int n) { return n == 512 || n == 1024; }
 
-bool fast_has_fused_deltas(const pds_stft_plan *plan) { return plan->fast.kind && fast_deltas_kind(plan->fast.kind); }
+bool fast_has_fused_deltas(const pds_stft_plan *plan) {
+  const FastTables &ft = plan->fast;
+  return ft.kind && fast_deltas_kind(ft.kind) && ft.rsn_rounds >= 1 && ft.rsn_rounds <= 2 &&
+         (!plan->d.include_energy || ft.rs_eslot >= 0);
+}
+
+// chunk_prefix[b] = chunks of GROUPS frames in front of utterance b, [B] = all of them: one workgroup,
+// a thread sums a contiguous slice of the utterances, the slices are scanned through LDS
+__global__ __launch_bounds__(1024) void chunk_prefix_kernel(const int64_t *nframes, int B, int groups, int64_t *prefix) {
+  __shared__ int64_t part[1024];
+  const int per = (B + 1023) / 1024, lo = threadIdx.x * per, hi = lo + per < B ? lo + per : B;
+  int64_t sum = 0;
+  for (int b = lo; b < hi; ++b) sum += (nframes[b] + groups - 1) / groups;
+  part[threadIdx.x] = sum;
+  __syncthreads();
+  for (int step = 1; step < 1024; step <<= 1) {
+    const int64_t add = threadIdx.x >= (unsigned)step ? part[threadIdx.x - step] : 0;
+    __syncthreads();
+    part[threadIdx.x] += add;
+    __syncthreads();
+  }
+  int64_t run = part[threadIdx.x] - sum;  // exclusive
+  for (int b = lo; b < hi; ++b) {
+    prefix[b] = run;
+    run += (nframes[b] + groups - 1) / groups;
+  }
+  if (threadIdx.x == 1023) prefix[B] = part[1023];
+}
 
 template <int N1, int N2, int NROWS, int MINW>
 static int32_t launch_wave(const pds_stft_plan *plan, const BatchArgs &a) {
   using G = WaveGeom<N1, N2, NROWS>;
-  constexpr int CU_WAVES = 4 * MINW;  // resident waves per CU that the register budget allows
+  // resident waves per CU that the register budget allows; the fused statics + deltas instantiations
+  // hold their window in registers and run three waves per SIMD where the others run four
+  constexpr int DMINW = MINW > 3 ? 3 : MINW;
+  constexpr int CU_WAVES_STFT = 4 * MINW;
+  const int CU_WAVES = a.dl_K > 0 ? 4 * DMINW : CU_WAVES_STFT;
   const FastTables &ft = plan->fast;
   FastParams p;
   p.sig = a.d_signal;
@@ -1274,7 +1401,16 @@ static int32_t launch_wave(const pds_stft_plan *plan, const BatchArgs &a) {
   // stay in global memory.
   const size_t lds_cu = 160 * 1024;
   const size_t per_wave = (size_t)G::EXCH_F2 * 8;
-  const int shapes[4][2] = {{CU_WAVES / 2, 2}, {CU_WAVES, 1}, {CU_WAVES * 3 / 4, 1}, {CU_WAVES * 5 / 8, 1}};
+  int shapes[4][2] = {{CU_WAVES / 2, 2}, {CU_WAVES, 1}, {CU_WAVES * 3 / 4, 1}, {CU_WAVES * 5 / 8, 1}};
+  if (CU_WAVES % 8 != 0) {
+    // (three waves per SIMD: two workgroups of six waves do not tile the four SIMDs -- the second one of a
+    // CU waited for the first to finish, measured as a launch twice as long -- one of twelve does)
+    shapes[0][0] = CU_WAVES, shapes[0][1] = 1;
+    shapes[1][0] = CU_WAVES * 2 / 3, shapes[1][1] = 1;
+    shapes[2][0] = CU_WAVES / 3, shapes[2][1] = 1;
+    shapes[3][0] = CU_WAVES / 3, shapes[3][1] = 1;
+  }
+  constexpr int CU_WAVES_K = CU_WAVES_STFT;  // launch bound of the instantiations below
   int waves = CU_WAVES / 2, wgs_per_cu = 2;
   bool in_lds = false;
   // Filter walk: the plan's preferred one (fast_tables_create: fewest 16-byte LDS reads per item, or
@@ -1285,13 +1421,15 @@ static int32_t launch_wave(const pds_stft_plan *plan, const BatchArgs &a) {
   p.num_filts = plan->d.num_filts;
   const bool pre = a.preemph != 0.0;
   int walk = 0;
-  for (int cand = (G::GROUPS == 4) ? ft.walk : 0; cand >= 0 && !in_lds; --cand) {
+  // (fused deltas exist for the row-segment walk only: take it whatever the plan prefers)
+  const bool dl = a.dl_K > 0 && ft.rsn_rounds > 0;  // (its own table: numbered order)
+  for (int cand = (G::GROUPS == 4) ? (dl ? 2 : ft.walk) : 0; cand >= 0 && !in_lds; --cand) {
     // (no segmented variant of the fused pre-emphasis kernel)
-    if ((cand == 2 && ft.rs_rounds == 0) || (cand == 1 && (ft.seg_rounds == 0 || pre || a.in_f64))) continue;
-    const int meta_ints = cand == 2 ? ft.rs_rounds * 64 : cand == 1 ? ft.seg_meta_ints : ft.ell_slots * N2;
+    if ((cand == 2 && !dl && ft.rs_rounds == 0) || (cand == 1 && (ft.seg_rounds == 0 || pre || a.in_f64))) continue;
+    const int meta_ints = cand == 2 ? (dl ? ft.rsn_rounds : ft.rs_rounds) * 64 : cand == 1 ? ft.seg_meta_ints : ft.ell_slots * N2;
     const int meta_pad = (std::max(meta_ints, USLOTS * N2) + 3) / 4 * 4;
     const size_t fixed = (size_t)N2 * 8 + (size_t)meta_pad * 4;
-    const size_t table_bytes = (size_t)(cand == 2 ? ft.rs_wfloats : cand == 1 ? ft.seg_wfloats : ft.ell_wfloats) * 4;
+    const size_t table_bytes = (size_t)(cand == 2 ? (dl ? ft.rsn_wfloats : ft.rs_wfloats) : cand == 1 ? ft.seg_wfloats : ft.ell_wfloats) * 4;
     // (segment sums live behind P in the wave's area)
     if (cand == 1 && (size_t)G::GROUPS * G::PSTR * 4 + (size_t)ft.seg_rounds * 64 * 16 > per_wave) continue;
     for (const auto &shape : shapes)
@@ -1310,11 +1448,11 @@ static int32_t launch_wave(const pds_stft_plan *plan, const BatchArgs &a) {
       p.seg_rounds = ft.seg_rounds;
       p.seg_len = ft.seg_len;
     } else if (in_lds && cand == 2) {
-      p.ell_w = ft.d_rs_w;
-      p.ell_meta = ft.d_rs_meta;
-      p.ell_wfloats = ft.rs_wfloats;
-      p.seg_rounds = ft.rs_rounds;
-      p.seg_len = ft.rs_len;
+      p.ell_w = dl ? ft.d_rsn_w : ft.d_rs_w;
+      p.ell_meta = dl ? ft.d_rsn_meta : ft.d_rs_meta;
+      p.ell_wfloats = dl ? ft.rsn_wfloats : ft.rs_wfloats;
+      p.seg_rounds = dl ? ft.rsn_rounds : ft.rs_rounds;
+      p.seg_len = dl ? ft.rsn_len : ft.rs_len;
     }
     if (in_lds) walk = cand;
   }
@@ -1338,12 +1476,12 @@ static int32_t launch_wave(const pds_stft_plan *plan, const BatchArgs &a) {
   const size_t smem = waves * per_wave + fixed + (in_lds ? table_bytes : 0);
   constexpr bool W4 = G::GROUPS == 4;  // the walks over four frames exist for the 16-lane geometries
   const bool seg = W4 && walk == 1, rsg = W4 && walk == 2;
-  auto kern = pre      ? (rsg ? stft_wave_kernel<N1, N2, NROWS, CU_WAVES, MINW, true, true, false, 0, W4>
-                              : stft_wave_kernel<N1, N2, NROWS, CU_WAVES, MINW, true, true>)
-              : rsg    ? stft_wave_kernel<N1, N2, NROWS, CU_WAVES, MINW, true, false, false, 0, W4>
-              : seg    ? stft_wave_kernel<N1, N2, NROWS, CU_WAVES, MINW, true, false, W4>
-              : in_lds ? stft_wave_kernel<N1, N2, NROWS, CU_WAVES, MINW, true, false>
-                       : stft_wave_kernel<N1, N2, NROWS, CU_WAVES, MINW, false, false>;
+  auto kern = pre      ? (rsg ? stft_wave_kernel<N1, N2, NROWS, CU_WAVES_K, MINW, true, true, false, 0, W4>
+                              : stft_wave_kernel<N1, N2, NROWS, CU_WAVES_K, MINW, true, true>)
+              : rsg    ? stft_wave_kernel<N1, N2, NROWS, CU_WAVES_K, MINW, true, false, false, 0, W4>
+              : seg    ? stft_wave_kernel<N1, N2, NROWS, CU_WAVES_K, MINW, true, false, W4>
+              : in_lds ? stft_wave_kernel<N1, N2, NROWS, CU_WAVES_K, MINW, true, false>
+                       : stft_wave_kernel<N1, N2, NROWS, CU_WAVES_K, MINW, false, false>;
   // matrix-pipe front end: the 32 x 16 geometry with LDS-resident filter tables, when the plan has
   // its tables for this row count
   constexpr int MFS = (N1 == 32 && N2 == 16) ? mfma_front_steps(NROWS) : 0;
@@ -1351,11 +1489,11 @@ static int32_t launch_wave(const pds_stft_plan *plan, const BatchArgs &a) {
   if constexpr (MFS > 0) {
     if (in_lds && ft.d_mf_tab && ft.mf_rows == NROWS) {
       mf = true;
-      kern = pre   ? (rsg ? stft_wave_kernel<N1, N2, NROWS, CU_WAVES, MINW, true, true, false, MFS, W4>
-                          : stft_wave_kernel<N1, N2, NROWS, CU_WAVES, MINW, true, true, false, MFS>)
-             : rsg ? stft_wave_kernel<N1, N2, NROWS, CU_WAVES, MINW, true, false, false, MFS, W4>
-             : seg ? stft_wave_kernel<N1, N2, NROWS, CU_WAVES, MINW, true, false, W4, MFS>
-                   : stft_wave_kernel<N1, N2, NROWS, CU_WAVES, MINW, true, false, false, MFS>;
+      kern = pre   ? (rsg ? stft_wave_kernel<N1, N2, NROWS, CU_WAVES_K, MINW, true, true, false, MFS, W4>
+                          : stft_wave_kernel<N1, N2, NROWS, CU_WAVES_K, MINW, true, true, false, MFS>)
+             : rsg ? stft_wave_kernel<N1, N2, NROWS, CU_WAVES_K, MINW, true, false, false, MFS, W4>
+             : seg ? stft_wave_kernel<N1, N2, NROWS, CU_WAVES_K, MINW, true, false, W4, MFS>
+                   : stft_wave_kernel<N1, N2, NROWS, CU_WAVES_K, MINW, true, false, false, MFS>;
     }
   }
   // float64 samples (pds_stft_batch_f64in): the common power-of-two geometries, LDS-resident tables,
@@ -1370,39 +1508,43 @@ static int32_t launch_wave(const pds_stft_plan *plan, const BatchArgs &a) {
       }
       mf = false;
       if (a.out_f64)
-        kern = rsg ? stft_wave_kernel<N1, N2, NROWS, CU_WAVES, MINW, true, false, false, 0, W4, double, double>
-                   : stft_wave_kernel<N1, N2, NROWS, CU_WAVES, MINW, true, false, false, 0, false, double, double>;
+        kern = rsg ? stft_wave_kernel<N1, N2, NROWS, CU_WAVES_K, MINW, true, false, false, 0, W4, double, double>
+                   : stft_wave_kernel<N1, N2, NROWS, CU_WAVES_K, MINW, true, false, false, 0, false, double, double>;
       else if (pre)
-        kern = rsg ? stft_wave_kernel<N1, N2, NROWS, CU_WAVES, MINW, true, true, false, 0, W4, double, float>
-                   : stft_wave_kernel<N1, N2, NROWS, CU_WAVES, MINW, true, true, false, 0, false, double, float>;
+        kern = rsg ? stft_wave_kernel<N1, N2, NROWS, CU_WAVES_K, MINW, true, true, false, 0, W4, double, float>
+                   : stft_wave_kernel<N1, N2, NROWS, CU_WAVES_K, MINW, true, true, false, 0, false, double, float>;
       else
-        kern = rsg ? stft_wave_kernel<N1, N2, NROWS, CU_WAVES, MINW, true, false, false, 0, W4, double, float>
-                   : stft_wave_kernel<N1, N2, NROWS, CU_WAVES, MINW, true, false, false, 0, false, double, float>;
+        kern = rsg ? stft_wave_kernel<N1, N2, NROWS, CU_WAVES_K, MINW, true, false, false, 0, W4, double, float>
+                   : stft_wave_kernel<N1, N2, NROWS, CU_WAVES_K, MINW, true, false, false, 0, false, double, float>;
       f64_which = 12 + (a.out_f64 ? 4 : pre ? 2 : 0) + (rsg ? 1 : 0);
     } else {
       set_error("stft_batch_f64in: no fused float64-input kernel for this transform size");
       return PDS_ERR_INVALID;
     }
   }
-  // fused statics + deltas (pds_stft_deltas_batch_f32): run scheduling, see the kernel
+  // fused statics + deltas (pds_stft_deltas_batch_f32): row-segment walk with at most two rounds and
+  // a spare lane for the energy, see the kernel
   int dl_which = -1;
   if (a.dl_K > 0) {
     constexpr bool DELTAS = fast_deltas_kind(N1 * N2) && G::GROUPS == 4;
     if constexpr (DELTAS) {
-      if (!in_lds || pre || a.in_f64 || seg) {
-        set_error("stft_deltas_batch: not served for this plan and call (filter table outside LDS, segmented walk, "
-                  "fused pre-emphasis or float64 samples)");
+      const int staged = ((a.dl_K + 1) * (plan->d.num_filts + (plan->d.include_energy ? 1 : 0)) + 3) / 4 * 16 + 64;  // floats
+      if (!in_lds || pre || a.in_f64 || !rsg || !dl || ft.rsn_rounds > 2 || (plan->d.include_energy && ft.rs_eslot < 0) ||
+          staged > G::EXCH_F2 * 2) {
+        set_error("stft_deltas_batch: not served for this plan and call (needs the row-segment filter walk with at "
+                  "most two rounds in LDS, float32 samples, no fused pre-emphasis)");
         return PDS_ERR_INVALID;
       }
       mf = false;
-      kern = a.dl_K == 1
-                 ? (rsg ? stft_wave_kernel<N1, N2, NROWS, CU_WAVES, MINW, true, false, false, 0, true, float, float, 1>
-                        : stft_wave_kernel<N1, N2, NROWS, CU_WAVES, MINW, true, false, false, 0, false, float, float, 1>)
-                 : (rsg ? stft_wave_kernel<N1, N2, NROWS, CU_WAVES, MINW, true, false, false, 0, true, float, float, 2>
-                        : stft_wave_kernel<N1, N2, NROWS, CU_WAVES, MINW, true, false, false, 0, false, float, float, 2>);
-      dl_which = 18 + (a.dl_K - 1) * 2 + (rsg ? 1 : 0);
-      for (int j = 0; j < 16; ++j) p.dl_taps[j] = a.dl_taps[j];
+      kern = a.dl_K == 1 ? stft_wave_kernel<N1, N2, NROWS, 4 * DMINW, DMINW, true, false, false, 0, true, float, float, 1>
+                         : stft_wave_kernel<N1, N2, NROWS, 4 * DMINW, DMINW, true, false, false, 0, true, float, float, 2>;
+      dl_which = 18 + (a.dl_K - 1);
+      for (int j = 0; j < 5; ++j) p.dl_f1[j] = (float)a.dl_taps[j];
+      for (int j = 0; j < 9; ++j) p.dl_f2[j] = a.dl_K > 1 ? (float)a.dl_taps[5 + j] : 0.0f;
       p.dl_inner = plan->d.num_filts + (plan->d.include_energy ? 1 : 0);
+      p.dl_eslot = plan->d.include_energy ? ft.rs_eslot : -1;
+      p.chunk_prefix = a.d_chunk_prefix;
+      p.dl_debug = std::getenv("PDS_DL_DEBUG") ? std::atoi(std::getenv("PDS_DL_DEBUG")) : 0;
     } else {
       set_error("stft_deltas_batch: no fused kernel for this transform size");
       return PDS_ERR_INVALID;
@@ -1427,24 +1569,12 @@ static int32_t launch_wave(const pds_stft_plan *plan, const BatchArgs &a) {
   const int64_t grid_waves = grid * waves;
   p.step_utts = (int)(grid_waves / chunks);
   p.step_chunks = (int)(grid_waves % chunks);
-  p.run_len = p.runs_per_utt = p.total_runs = 0;
   if (a.dl_K > 0) {
-    // runs: about two per workgroup of a full grid, at least 8 chunks (the two halo chunks are
-    // computed twice), at most an utterance
-    const int64_t full = (int64_t)ft.num_cus * wgs_per_cu;
-    int64_t run_len = (chunks * a.B + 2 * full - 1) / (2 * full);
-    run_len = std::min<int64_t>(std::max<int64_t>(run_len, 8), chunks);
-    if (const char *force = std::getenv("PDS_RUN_LEN"))  // (measurement: statics of shorter runs stay in cache)
-      run_len = std::min<int64_t>(std::max<int64_t>(std::atol(force), 2), chunks);
-    const int64_t per_utt = (chunks + run_len - 1) / run_len;
-    if (per_utt * a.B > 0x7fffffff) {
-      set_error("stft_deltas_batch: too many runs in one call");
-      return PDS_ERR_INVALID;
-    }
-    p.run_len = (int)run_len;
-    p.runs_per_utt = (int)per_utt;
-    p.total_runs = (int)(per_utt * a.B);
-    grid = std::min<int64_t>(full, p.total_runs);
+    // the utterances' chunk counts summed up on the device, then one stretch of chunks per wave
+    grid = std::min<int64_t>((int64_t)ft.num_cus * wgs_per_cu, std::max<int64_t>(1, (chunks * a.B + 4 * waves - 1) / (4 * waves)));
+    hipLaunchKernelGGL(chunk_prefix_kernel, dim3(1), dim3(1024), 0, a.stream, a.d_nframes, a.B, G::GROUPS,
+                       a.d_chunk_prefix);
+    PDS_HIP(hipGetLastError());
   }
   hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(waves * 64), smem, a.stream, p);
   PDS_HIP(hipGetLastError());
@@ -1703,7 +1833,20 @@ int32_t fast_tables_create(pds_stft_plan *plan, const double *window, const int3
       ft.rs_wfloats = (int)rs.w.size();
       ft.rs_reads = rs.reads_per_lane();
       ft.rs_cost = rs.cost;
-      rc = upload(&ft.d_rs_w, rs.w.data(), rs.w.size());
+      // fused statics + deltas launches (transform sizes with such instantiations, at most two rounds): the
+      // table in numbered order, and a lane that finishes no filter to carry the energy column
+      RsegTables rn;
+      ft.rs_eslot = -1;
+      if (rc == PDS_OK && fast_deltas_kind(N) && build_rseg(d.num_filts, row_ptr, col, val, N / 2 + 1, area_floats / 4, 2, rn, true)) {
+        ft.rsn_rounds = rn.rounds;
+        ft.rsn_len = rn.seg_len;
+        ft.rsn_wfloats = (int)rn.w.size();
+        for (size_t at = 0; at < rn.meta.size() && ft.rs_eslot < 0; ++at)
+          if ((rn.meta[at] >> 16) == 0) ft.rs_eslot = (int)at;
+        rc = upload(&ft.d_rsn_w, rn.w.data(), rn.w.size());
+        if (rc == PDS_OK) rc = upload(&ft.d_rsn_meta, rn.meta.data(), rn.meta.size());
+      }
+      if (rc == PDS_OK) rc = upload(&ft.d_rs_w, rs.w.data(), rs.w.size());
       if (rc == PDS_OK) rc = upload(&ft.d_rs_meta, rs.meta.data(), rs.meta.size());
     }
   }
@@ -1784,6 +1927,8 @@ void fast_tables_destroy(pds_stft_plan *plan) {
   (void)hipFree(ft.d_tw_special);
   (void)hipFree(ft.d_mf_tab);
   (void)hipFree(ft.d_rs_w);
+  (void)hipFree(ft.d_rsn_w);
+  (void)hipFree(ft.d_rsn_meta);
   (void)hipFree(ft.d_rs_meta);
   (void)hipFree(ft.d_seg_w);
   (void)hipFree(ft.d_seg_meta);
