@@ -96,6 +96,11 @@ extern "C" __attribute__((visibility("default"))) void pds_debug_set_stamp_buffe
 #ifndef PDS_STAGGER
 #define PDS_STAGGER 0
 #endif
+// Experiment (-DPDS_NT_STORE=1 | 2): non-temporal stores of the fused-deltas rows (1) and of the row-segment
+// walk's coefficients (2)
+#ifndef PDS_NT_STORE
+#define PDS_NT_STORE 0
+#endif
 // filter-walk depth of the geometries that run two waves per SIMD or fewer (256 registers and more)
 // (measured, tools/ab_libs.sh: segmented walk four steps deep at N = 1024, Gammatone-64 +3 %; ELL walk four
 // steps deep: N = 4096 +0.6 %, N = 2048 -0.5 %)
@@ -281,6 +286,16 @@ __global__ __launch_bounds__(MAXWAVES * 64, MINW) void stft_wave_kernel(const Fa
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int g = lane / N2, r = lane % N2;
+  // PAIR (float64 samples, 16 lanes per frame): the frame is loaded as 16-byte pairs of samples --
+  // an 8-byte load instruction of a wave costs the memory path as much as a 16-byte one
+  // (tools/vmem_microbench) -- so a lane receives residues 2s and 2s + 1 of one row, lanes 0..7 of the
+  // even rows, lanes 8..15 of the odd ones; lane s and lane s + 8 then swap one sample of every pair
+  // (a masked row_ror:8 each way) and lane s owns residue 2s, lane s + 8 residue 2s + 1 of EVERY row.
+  // `rho` is the residue (n2) whose samples, window and twiddles the lane holds until the exchange;
+  // it is `r` everywhere else.
+  constexpr bool PAIR = !std::is_same<TIN, float>::value && N2 == 16 && MF == 0;
+  const int rho = PAIR ? ((r & 7) * 2 + (r >> 3)) : r;
+  constexpr int LOADSPAN = PAIR ? (NROWS + 1) / 2 * 32 : NROWS * N2;  // samples a frame's direct loads reach over
   [[maybe_unused]] const unsigned long long st_entry = PDS_STAMPS ? __builtin_readcyclecounter() : 0;
   float *wbase = smem + wave * (G::EXCH_F2 * 2);
   float2 *exch = reinterpret_cast<float2 *>(wbase) + g * COLS * RS;
@@ -329,10 +344,10 @@ __global__ __launch_bounds__(MAXWAVES * 64, MINW) void stft_wave_kernel(const Fa
     }
   } else {
 #pragma unroll
-    for (int n1 = 0; n1 < NROWS; ++n1) win[n1] = p.win_lane[r * N1 + n1];
+    for (int n1 = 0; n1 < NROWS; ++n1) win[n1] = p.win_lane[rho * N1 + n1];
 #pragma unroll
     for (int k1 = 1; k1 <= NREG; ++k1) {
-      const float2 t = p.tw_lane[r * COLS + k1];
+      const float2 t = p.tw_lane[rho * COLS + k1];
       twr[k1] = t.x;
       twi[k1] = t.y;
     }
@@ -457,7 +472,11 @@ __global__ __launch_bounds__(MAXWAVES * 64, MINW) void stft_wave_kernel(const Fa
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
             F4 o = {val[q].x, val[q].y, val[q].z, val[q].w};
+#if PDS_NT_STORE & 1
+            __builtin_nontemporal_store(o, reinterpret_cast<F4 *>(orow + (int64_t)q * p.out_stride + 4 * l));
+#else
             *reinterpret_cast<F4 *>(orow + (int64_t)q * p.out_stride + 4 * l) = o;
+#endif
           }
         }
       } else {
@@ -715,12 +734,12 @@ __global__ __launch_bounds__(MAXWAVES * 64, MINW) void stft_wave_kernel(const Fa
       int start = start0 + __mul24(g, S);  // (24-bit multiplies issue at full rate, 32-bit ones at a quarter)
       int wmode = 0;
       if (!(tb + G::GROUPS <= nfr && start0 >= (PRE ? 1 : 0) &&
-            start0 + (G::GROUPS - 1) * S + NROWS * N2 <= n)) {
+            start0 + (G::GROUPS - 1) * S + LOADSPAN <= n)) {
         valid = tb + g < nfr;
         start = (valid ? tb + g : nfr - 1) * S - p.pad_left;
         int mode = 0;
         // (with fused pre-emphasis the direct loads also read x[start - 1])
-        if (start < (PRE ? 1 : 0) || start + NROWS * N2 > n) mode = 1;
+        if (start < (PRE ? 1 : 0) || start + LOADSPAN > n) mode = 1;
         if (start < -n || start + L > 2 * n) mode = 2;
         wmode = __builtin_amdgcn_readfirstlane(__any(mode == 2) ? 2 : (__any(mode == 1) ? 1 : 0));
       }
@@ -730,7 +749,35 @@ __global__ __launch_bounds__(MAXWAVES * 64, MINW) void stft_wave_kernel(const Fa
         // Lanes past the frame's end in the last row read samples of the next frame; the
         // window (exactly 0 there, applied with the 0 * x = 0 multiply) removes them.
         const TIN *xp = x + (start + r);
-        if constexpr (!std::is_same<TIN, float>::value) {
+        if constexpr (PAIR) {
+          typedef double D2 __attribute__((ext_vector_type(2), aligned(8)));
+          const TIN *xq = x + (start + 2 * r);  // the lane's pair inside every block of two rows
+          // (all loads first: the lane exchanges below are convergent operations, which the compiler
+          // does not move loads across -- interleaved in the source, every load waited for the one before)
+          constexpr int NP = (NROWS + 1) / 2;
+          D2 w2[NP];
+          [[maybe_unused]] double wprev[PRE ? NP : 1];
+#pragma unroll
+          for (int j = 0; j < NP; ++j) {
+            w2[j] = *reinterpret_cast<const D2 *>(xq + 32 * j);
+            if constexpr (PRE) wprev[j] = xq[32 * j - 1];
+          }
+#pragma unroll
+          for (int j = 0; j < NP; ++j) {
+            double u = w2[j].x, v = w2[j].y;
+            if constexpr (PRE) {
+              // float64 pre-emphasis before the rounding (pre.py:140-149): v's predecessor is u
+              v = preemph_sample(w2[j].y, w2[j].x, (TIN)p.preemph_d);
+              u = preemph_sample(w2[j].x, wprev[j], (TIN)p.preemph_d);
+            }
+            const float fu = (float)u, fv = (float)v;
+            // lanes 8..15 take residue 2s + 1 of the even row from lane s; lanes 0..7 take residue 2s of
+            // the odd row from lane s + 8 (row_ror:8 = lane ^ 8, bank masks pick the receiving half)
+            a[2 * j] = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(fu), __float_as_int(fv), 0x128, 0xf, 0xc, false));
+            if (2 * j + 1 < NROWS)
+              a[2 * j + 1] = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(fv), __float_as_int(fu), 0x128, 0xf, 0x3, false));
+          }
+        } else if constexpr (!std::is_same<TIN, float>::value) {
           // float64 samples: 8-byte loads, pre-emphasis in float64 (bit-identical to the reference's
           // own pass, pre.py:140-149), one rounding to float32
 #pragma unroll
@@ -767,7 +814,7 @@ __global__ __launch_bounds__(MAXWAVES * 64, MINW) void stft_wave_kernel(const Fa
         float *tmp = wbase;
 #pragma unroll 1
         for (int n1 = 0; n1 < NROWS; ++n1) {
-          const int idx = n1 * N2 + r;
+          const int idx = n1 * N2 + rho;
           float v = 0.0f;
           if (idx < L) {
             int i = start + idx;
@@ -798,7 +845,7 @@ __global__ __launch_bounds__(MAXWAVES * 64, MINW) void stft_wave_kernel(const Fa
         // masked against L.  The limit goes through an opaque asm so that the compares are made
         // here, per item: hoisted out of the loop they would sit in one scalar register pair per
         // row for the whole kernel.
-        int lim = L - r;
+        int lim = L - rho;
         asm volatile("" : "+v"(lim));
 #pragma unroll
         for (int n1 = 0; n1 < NROWS; ++n1) {
@@ -835,8 +882,8 @@ __global__ __launch_bounds__(MAXWAVES * 64, MINW) void stft_wave_kernel(const Fa
       PDS_PHASE(1);
       {
         float *row0 = reinterpret_cast<float *>(exch);
-        row0[r] = even_sum;
-        row0[N2 + r] = odd_sum;
+        row0[rho] = even_sum;
+        row0[N2 + rho] = odd_sum;
       }
 #pragma unroll
       for (int k1 = 1; k1 <= NREG; ++k1) {
@@ -847,7 +894,7 @@ __global__ __launch_bounds__(MAXWAVES * 64, MINW) void stft_wave_kernel(const Fa
           Ar[k1] = v.x;
           Ai[k1] = v.y;
         } else {
-          exch[k1 * RS + r] = v;
+          exch[k1 * RS + rho] = v;
         }
       }
     }
@@ -1174,7 +1221,11 @@ __global__ __launch_bounds__(MAXWAVES * 64, MINW) void stft_wave_kernel(const Fa
           float v = vals[gg];
           // max(val, floor) as Python evaluates it: a NaN stays a NaN (compute.py:459)
           if (p.use_log) v = fast_log(p.log_floor > v ? p.log_floor : v);
+#if PDS_NT_STORE & 2
+          if (DLT == 0 && f >= 0 && gg < frames_here) __builtin_nontemporal_store((TOUT)v, dst + (int64_t)gg * p.out_stride);
+#else
           if (DLT == 0 && f >= 0 && gg < frames_here) dst[(int64_t)gg * p.out_stride] = (TOUT)v;
+#endif
           logged[gg] = v;
         }
       };
