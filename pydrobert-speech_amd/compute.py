@@ -491,7 +491,7 @@ class ShortTimeFourierTransformFrameComputer(LinearFilterBankFrameComputer):
         return out
 
     def launch_with_deltas(self, signal, layout: "PackedLayout", deltas, out=None, pad_left=None,
-                           fused: bool = False):
+                           fused: Optional[bool] = None):
         """Statics and ``deltas`` (a :class:`pydrobert_speech_amd.post.Deltas`) of a packed batch
 
         Returns the ``(total_rows, (K + 1) num_coeffs)`` float32 tensor: row r holds the features of
@@ -500,8 +500,13 @@ class ShortTimeFourierTransformFrameComputer(LinearFilterBankFrameComputer):
         (``pds_stft_deltas_batch_f32``: transform sizes 512 and 1024, mel-like banks, ``Deltas(1 or 2)``
         with the default context window and padding): the statics are the same bit for bit, the deltas
         are formed in float32 from coefficients held in registers (within a few float32 ulps of the
-        statics of the float64-accumulated ones) and nothing is read back from memory.
+        statics of the float64-accumulated ones) and nothing is read back from memory.  It is what runs
+        when ``fused`` is left at ``None`` and the plan has it (1.34 x the rate of the two launches on
+        BASELINE.json configs[2]); ``fused=False`` keeps the two launches, whose deltas are numpy's bit
+        for bit.
         """
+        if fused is None:
+            fused = True
         torch = _native.require_device()
         lib = _native.lib()
         C, K = self.num_coeffs, deltas.num_deltas

@@ -188,10 +188,13 @@ def test_full_size_linearity_property(computers, golden_tables):
         assert_features_close(y2[b * 1000 : (b + 1) * 1000].cpu().numpy(), want, **F32)
 
 
-def test_full_size_statics_plus_deltas_chain(computers):
+@pytest.mark.parametrize("fused", [True, False], ids=["one-launch", "two-launches"])
+def test_full_size_statics_plus_deltas_chain(computers, fused):
     # BASELINE.json configs[2] per GPU at the benchmark batch: 80 mel + energy written with row stride 243,
-    # Deltas(2) beside them.  Scaling the signal shifts the statics by 2 log a and leaves the deltas alone
-    # (the filters sum to zero); an utterance alone gives the same rows.
+    # Deltas(2) beside them -- by the one launch that forms the deltas from the coefficients in its registers
+    # (pds_stft_deltas_batch_f32, what bench.py times) and by the STFT launch followed by the deltas launch.
+    # Scaling the signal shifts the statics by 2 log a and leaves the deltas alone (the filters sum to
+    # zero); an utterance alone gives the same rows.
     import torch
 
     from pydrobert_speech_amd.post import Deltas
@@ -206,9 +209,10 @@ def test_full_size_statics_plus_deltas_chain(computers):
     deltas = Deltas(2)
 
     def chain(sig, lay):
-        out = torch.empty((lay.total_rows, 3 * C), dtype=torch.float32, device=sig.device)
-        comp.launch(sig, lay, out=out)
-        deltas.apply_rows(out[:, :C], lay.row_offsets, out=out)
+        out = torch.full((lay.total_rows, 3 * C), float("nan"), dtype=torch.float32, device=sig.device)
+        if fused:
+            assert comp._native_plan(sig.device).has_fused_deltas
+        comp.launch_with_deltas(sig, lay, deltas, out=out, fused=fused)
         return out
 
     y1 = chain(x, layout)
@@ -222,10 +226,13 @@ def test_full_size_statics_plus_deltas_chain(computers):
     one = comp.prepare_layout([0], [n], device=x.device)
     y3 = chain(x[b * n : (b + 1) * n].clone(), one)
     assert torch.equal(y3, y2[b * 1000 : (b + 1) * 1000])
-    # the deltas of the launch against the oracle's, on one utterance's statics
-    stat = y2[:1000, :C].cpu().numpy()
-    want = orc.deltas(stat, axis=0, num_deltas=2, target_axis=-1)
-    assert np.allclose(y2[:1000].cpu().numpy(), want, rtol=1e-6, atol=1e-6)
+    # the deltas of the launch against the oracle's, on some utterances' statics (the one launch accumulates
+    # in float32: a few ulps of the statics, which are ~20 here)
+    for b in (0, 333, B - 1):
+        stat = y2[b * 1000 : (b + 1) * 1000, :C].cpu().numpy()
+        want = orc.deltas(stat, axis=0, num_deltas=2, target_axis=-1)
+        tol = 1e-5 if fused else 1e-6
+        assert np.allclose(y2[b * 1000 : (b + 1) * 1000].cpu().numpy(), want, rtol=tol, atol=tol)
 
 
 def test_full_size_gammatone_cmvn_chain(computers):
