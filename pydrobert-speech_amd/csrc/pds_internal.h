@@ -47,7 +47,12 @@ struct FastTables {
   int32_t *d_rsn_meta = nullptr;
   int rsn_rounds = 0, rsn_len = 0, rsn_wfloats = 0;
   int rs_eslot = -1;               // round * 64 + lane of a lane that finishes no filter (-1: every lane does)
-  int walk = 0;  // preferred filter walk: 0 ELL, 1 segments (dense banks), 2 row segments
+  // matrix-pipe segment walk (mseg_tables.h; 16-lane power-of-two geometries, dense banks): 0 rounds = not built
+  float *d_ms_w = nullptr;         // [ms_rounds][ms_len / 4][64][4]
+  int32_t *d_ms_meta = nullptr;    // [ms_rounds * 16] unit first bins, then [num_filts] first partial slot | units << 16
+  int ms_rounds = 0, ms_len = 0, ms_wfloats = 0, ms_meta_ints = 0;
+  long ms_reads = 0;
+  int walk = 0;  // preferred filter walk: 0 ELL, 1 segments (dense banks), 2 row segments, 3 matrix-pipe segments
   long rs_reads = 0, rs_cost = 0, ell_reads = 0, seg_reads = 0;  // 16-byte LDS reads per lane and item of each walk
   // matrix-pipe front end (mfma_front.h; 32 x 16 geometry): device image of the tables, built for
   // the kernel instantiation of `mf_rows` rows (0 = not built: PDS_STFT_FRONT=valu, other geometry)

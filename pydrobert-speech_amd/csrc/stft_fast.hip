@@ -39,6 +39,7 @@
 #include "fft_inlane.h"
 #include "mfma_front.h"
 #include "rseg_tables.h"
+#include "mseg_tables.h"
 #include "pds_internal.h"
 
 namespace pds {
@@ -109,6 +110,10 @@ extern "C" __attribute__((visibility("default"))) void pds_debug_set_stamp_buffe
 #endif
 #ifndef PDS_ELL_DEEP_N
 #define PDS_ELL_DEEP_N 4096
+#endif
+// transform sizes from which dense banks take the matrix-pipe segment walk by default
+#ifndef PDS_MSEG_MIN_N
+#define PDS_MSEG_MIN_N 1024
 #endif
 #ifndef PDS_FILTER_UNROLL
 #define PDS_FILTER_UNROLL 2
@@ -254,7 +259,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // float64 like the reference's own pass), float64 features are widened at the store -- the dtype flow
 // of the reference's drivers (float64 audio in, compute.py:601 output dtype = input dtype) without
 // separate conversion passes over the signal and the features.
-template <int N1, int N2, int NROWS, int MAXWAVES, int MINW, bool ELL_LDS, bool PRE, bool SEG = false, int MF = 0,
+template <int N1, int N2, int NROWS, int MAXWAVES, int MINW, bool ELL_LDS, bool PRE, int SEG = 0, int MF = 0,
           bool RSG = false, typename TIN = float, typename TOUT = float, int DLT = 0>
 __global__ __launch_bounds__(MAXWAVES * 64, MINW) void stft_wave_kernel(const FastParams p) {
   // DLT = K > 0: Deltas(K, context_window 2, edge padding) of the features appended to every row by the
@@ -1280,6 +1285,89 @@ __global__ __launch_bounds__(MAXWAVES * 64, MINW) void stft_wave_kernel(const Fa
         float4 *part = reinterpret_cast<float4 *>(wbase + G::GROUPS * PSTR);
         constexpr int SEG_DEPTH = N >= PDS_SEG_DEEP_N ? 4 : 2;
         const int steps = p.seg_len >> 2;
+        if constexpr (SEG == 2) {
+          // Matrix-pipe form (mseg_tables.h): the filters in quads of four neighbours, a quad's bin range
+          // in units of seg_len bins, 16 units per round -- one per block of v_mfma_f32_4x4x1_16B_f32.
+          // Lane 4 b + i supplies the weight of filter i of block b's quad, lane 4 b + j the power of
+          // frame j, and lane 4 b + j receives the block's four filter sums for frame j: 256 exact
+          // float32 multiply-adds per instruction on the pipe the kernel leaves idle otherwise, for one
+          // 16-byte weight read and one 16-byte power read per four of them (the segmented walk below:
+          // five reads and sixteen vector multiply-adds per four bins of ONE filter).  Two accumulators
+          // take the bins alternately, so an instruction does not wait for the one before.
+          const int blk = lane >> 2, fr = lane & 3;
+          const float *Pj = wbase + fr * PSTR;
+          float *pf = reinterpret_cast<float *>(part) + fr;
+          // A round: ALL its operand reads (two 16-byte reads per four bins), then its matrix instructions;
+          // the reads of the NEXT round are issued before this round's instructions (two operand buffers),
+          // and a round's first bin is fetched two rounds ahead -- so neither an LDS round trip nor the
+          // table look-up in front of it is exposed per round.  (Measured at 1.5 waves per SIMD, Gammatone-64
+          // at N = 1024: reads and instructions of one round back to back take ~950 cycles per round for
+          // ~260 cycles of matrix pipe.)
+          const float4 *wbase4 = reinterpret_cast<const float4 *>(ellw_lds) + lane;
+          const int last = p.seg_rounds - 1;
+          auto meta_of = [&](int rd) { return meta_lds[(rd < last ? rd : last) * 16 + blk]; };
+          auto walk = [&](auto steps_c) {
+            constexpr int ST = decltype(steps_c)::value;
+            auto fetch = [&](float4 (&w)[ST], float4 (&x)[ST], const int rd, const int first) {
+              const float4 *wrow = wbase4 + __mul24(rd, ST) * 64;
+              const float4 *prow = reinterpret_cast<const float4 *>(Pj + first);
+#pragma unroll
+              for (int u = 0; u < ST; ++u) {
+                w[u] = wrow[u * 64];
+                x[u] = prow[u];
+              }
+            };
+            auto compute = [&](const float4 (&w)[ST], const float4 (&x)[ST], const int rd) {
+              f32x4 acc0 = {0.0f, 0.0f, 0.0f, 0.0f}, acc1 = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+              for (int u = 0; u < ST; ++u) {
+                acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(w[u].x, x[u].x, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(w[u].y, x[u].y, acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(w[u].z, x[u].z, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(w[u].w, x[u].w, acc1, 0, 0, 0);
+              }
+              // partial slot = unit * 4 + filter of the quad, a float4 over the frames
+              float *dst = pf + (rd * 16 + blk) * 16;
+              dst[0] = acc0[0] + acc1[0];
+              dst[4] = acc0[1] + acc1[1];
+              dst[8] = acc0[2] + acc1[2];
+              dst[12] = acc0[3] + acc1[3];
+            };
+            // (two buffers of 16 bins: 64 registers, which the 256-register geometries have; the others,
+            // and longer units, run one round at a time)
+            if constexpr (ST == 4 && MINW <= 2) {
+              float4 wa[ST], xa[ST], wb[ST], xb[ST];
+              int fb = meta_of(1), fc = meta_of(2);
+              fetch(wa, xa, 0, meta_of(0));
+#pragma unroll 1
+              for (int rd = 0; rd <= last; rd += 2) {
+                const int fd = meta_of(rd + 3), fe = meta_of(rd + 4);
+                if (rd < last) fetch(wb, xb, rd + 1, fb);
+                compute(wa, xa, rd);
+                if (rd >= last) break;
+                if (rd + 1 < last) fetch(wa, xa, rd + 2, fc);
+                compute(wb, xb, rd + 1);
+                fb = fd;
+                fc = fe;
+              }
+            } else {
+              int first = meta_of(0);
+#pragma unroll 1
+              for (int rd = 0; rd <= last; ++rd) {
+                const int next = meta_of(rd + 1);
+                float4 w[ST], x[ST];
+                fetch(w, x, rd, first);
+                compute(w, x, rd);
+                first = next;
+              }
+            }
+          };
+          if (steps == 4) {  // (mseg_tables.h builds units of 16 or 32 bins)
+            walk(inl::Int<4>{});
+          } else {
+            walk(inl::Int<8>{});
+          }
+        } else
         for (int q = 0; q < p.seg_rounds; ++q) {
           const int slot = q * 64 + lane;
           const int first = meta_lds[slot];
@@ -1313,14 +1401,17 @@ __global__ __launch_bounds__(MAXWAVES * 64, MINW) void stft_wave_kernel(const Fa
           }
           part[slot] = acc;
         }
+        if constexpr (PDS_STAMPS > 1) PDS_STAMP(4, 0);  // (diagnostic: the rounds go to slot 4, the sums and stores stay in 5)
         wave_sync();
-        const int *fmeta = meta_lds + p.seg_rounds * 64;
+        const int *fmeta = meta_lds + p.seg_rounds * (SEG == 2 ? 16 : 64);
+        constexpr int PSTEP = SEG == 2 ? 4 : 1;  // a filter's partial sums: consecutive slots, or a quad apart
         for (int f = lane; f < p.num_filts; f += 64) {
           const int fm = fmeta[f];
           const float4 *src = part + (fm & 0xffff);
           float4 sum = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
           for (int k = fm >> 16; k > 0; --k) {
-            const float4 v = *src++;
+            const float4 v = *src;
+            src += PSTEP;
             sum.x += v.x;
             sum.y += v.y;
             sum.z += v.z;
@@ -1474,15 +1565,18 @@ static int32_t launch_wave(const pds_stft_plan *plan, const BatchArgs &a) {
   int walk = 0;
   // (fused deltas exist for the row-segment walk only: take it whatever the plan prefers)
   const bool dl = a.dl_K > 0 && ft.rsn_rounds > 0;  // (its own table: numbered order)
+  constexpr bool MSG = G::GROUPS == 4 && inl::is_pow2(N1);  // matrix-pipe segment walk instantiated
   for (int cand = (G::GROUPS == 4) ? (dl ? 2 : ft.walk) : 0; cand >= 0 && !in_lds; --cand) {
+    if (cand == 3 && (!MSG || ft.ms_rounds == 0 || pre || a.in_f64)) continue;
     // (no segmented variant of the fused pre-emphasis kernel)
     if ((cand == 2 && !dl && ft.rs_rounds == 0) || (cand == 1 && (ft.seg_rounds == 0 || pre || a.in_f64))) continue;
-    const int meta_ints = cand == 2 ? (dl ? ft.rsn_rounds : ft.rs_rounds) * 64 : cand == 1 ? ft.seg_meta_ints : ft.ell_slots * N2;
+    const int meta_ints = cand == 3 ? ft.ms_meta_ints : cand == 2 ? (dl ? ft.rsn_rounds : ft.rs_rounds) * 64 : cand == 1 ? ft.seg_meta_ints : ft.ell_slots * N2;
     const int meta_pad = (std::max(meta_ints, USLOTS * N2) + 3) / 4 * 4;
     const size_t fixed = (size_t)N2 * 8 + (size_t)meta_pad * 4;
-    const size_t table_bytes = (size_t)(cand == 2 ? (dl ? ft.rsn_wfloats : ft.rs_wfloats) : cand == 1 ? ft.seg_wfloats : ft.ell_wfloats) * 4;
+    const size_t table_bytes = (size_t)(cand == 3 ? ft.ms_wfloats : cand == 2 ? (dl ? ft.rsn_wfloats : ft.rs_wfloats) : cand == 1 ? ft.seg_wfloats : ft.ell_wfloats) * 4;
     // (segment sums live behind P in the wave's area)
     if (cand == 1 && (size_t)G::GROUPS * G::PSTR * 4 + (size_t)ft.seg_rounds * 64 * 16 > per_wave) continue;
+    if (cand == 3 && (size_t)G::GROUPS * G::PSTR * 4 + (size_t)ft.ms_rounds * 64 * 16 > per_wave) continue;
     for (const auto &shape : shapes)
       if (shape[0] * per_wave + fixed + table_bytes <= lds_cu / shape[1]) {
         waves = shape[0];
@@ -1492,7 +1586,13 @@ static int32_t launch_wave(const pds_stft_plan *plan, const BatchArgs &a) {
       }
     p.ell_meta_pad = meta_pad;
     p.ell_meta_ints = meta_ints;
-    if (in_lds && cand == 1) {
+    if (in_lds && cand == 3) {
+      p.ell_w = ft.d_ms_w;
+      p.ell_meta = ft.d_ms_meta;
+      p.ell_wfloats = ft.ms_wfloats;
+      p.seg_rounds = ft.ms_rounds;
+      p.seg_len = ft.ms_len;
+    } else if (in_lds && cand == 1) {
       p.ell_w = ft.d_seg_w;
       p.ell_meta = ft.d_seg_meta;
       p.ell_wfloats = ft.seg_wfloats;
@@ -1526,10 +1626,11 @@ static int32_t launch_wave(const pds_stft_plan *plan, const BatchArgs &a) {
 #endif
   const size_t smem = waves * per_wave + fixed + (in_lds ? table_bytes : 0);
   constexpr bool W4 = G::GROUPS == 4;  // the walks over four frames exist for the 16-lane geometries
-  const bool seg = W4 && walk == 1, rsg = W4 && walk == 2;
+  const bool seg = W4 && (walk == 1 || walk == 3), rsg = W4 && walk == 2, mseg = MSG && walk == 3;
   auto kern = pre      ? (rsg ? stft_wave_kernel<N1, N2, NROWS, CU_WAVES_K, MINW, true, true, false, 0, W4>
                               : stft_wave_kernel<N1, N2, NROWS, CU_WAVES_K, MINW, true, true>)
               : rsg    ? stft_wave_kernel<N1, N2, NROWS, CU_WAVES_K, MINW, true, false, false, 0, W4>
+              : mseg   ? stft_wave_kernel<N1, N2, NROWS, CU_WAVES_K, MINW, true, false, MSG ? 2 : 0>
               : seg    ? stft_wave_kernel<N1, N2, NROWS, CU_WAVES_K, MINW, true, false, W4>
               : in_lds ? stft_wave_kernel<N1, N2, NROWS, CU_WAVES_K, MINW, true, false>
                        : stft_wave_kernel<N1, N2, NROWS, CU_WAVES_K, MINW, false, false>;
@@ -1538,7 +1639,7 @@ static int32_t launch_wave(const pds_stft_plan *plan, const BatchArgs &a) {
   constexpr int MFS = (N1 == 32 && N2 == 16) ? mfma_front_steps(NROWS) : 0;
   bool mf = false;
   if constexpr (MFS > 0) {
-    if (in_lds && ft.d_mf_tab && ft.mf_rows == NROWS) {
+    if (in_lds && ft.d_mf_tab && ft.mf_rows == NROWS && !mseg) {
       mf = true;
       kern = pre   ? (rsg ? stft_wave_kernel<N1, N2, NROWS, CU_WAVES_K, MINW, true, true, false, MFS, W4>
                           : stft_wave_kernel<N1, N2, NROWS, CU_WAVES_K, MINW, true, true, false, MFS>)
@@ -1607,6 +1708,7 @@ static int32_t launch_wave(const pds_stft_plan *plan, const BatchArgs &a) {
   static std::atomic<size_t> attr_smem[kDevices][22];
   const int which = dl_which >= 0    ? dl_which
                     : f64_which >= 0 ? f64_which
+                    : mseg           ? 20
                                      : (pre ? (rsg ? 5 : 2) : rsg ? 4 : seg ? 3 : (in_lds ? 1 : 0)) + (mf ? 6 : 0);
   const bool cached = plan->device >= 0 && plan->device < kDevices;
   if (!cached || smem > attr_smem[plan->device][which].load(std::memory_order_relaxed)) {
@@ -1901,6 +2003,22 @@ int32_t fast_tables_create(pds_stft_plan *plan, const double *window, const int3
       if (rc == PDS_OK) rc = upload(&ft.d_rs_meta, rs.meta.data(), rs.meta.size());
     }
   }
+  // Matrix-pipe segment walk (mseg_tables.h): built where the segmented walk is (dense banks), for the
+  // power-of-two 16-lane geometries
+  if (n2 == 16 && pow2 && rc == PDS_OK && ft.seg_rounds > 0) {
+    MsegTables ms;
+    const int area_floats = 4 * cols * (n2 + 2) * 2;  // WaveGeom::EXCH_F2 * 2
+    const int max_units = (area_floats - 4 * pstr) / 16;  // four float4 partial slots per unit behind P
+    if (build_mseg(d.num_filts, row_ptr, col, val, pstr, max_units, ms)) {
+      ft.ms_rounds = ms.rounds;
+      ft.ms_len = ms.seg_len;
+      ft.ms_wfloats = (int)ms.w.size();
+      ft.ms_meta_ints = (int)ms.meta.size();
+      ft.ms_reads = ms.reads_per_lane();
+      rc = upload(&ft.d_ms_w, ms.w.data(), ms.w.size());
+      if (rc == PDS_OK) rc = upload(&ft.d_ms_meta, ms.meta.data(), ms.meta.size());
+    }
+  }
   {
     const char *force = std::getenv("PDS_STFT_WALK");
     ft.walk = ft.seg_rounds > 0 ? 1 : 0;  // (the segmented walk's own criterion, above)
@@ -1912,12 +2030,16 @@ int32_t fast_tables_create(pds_stft_plan *plan, const double *window, const int3
     if (force && std::strcmp(force, "ell") == 0) ft.walk = 0;
     if (force && std::strcmp(force, "seg") == 0) ft.walk = ft.seg_rounds > 0 ? 1 : 0;
     if (force && std::strcmp(force, "rseg") == 0) ft.walk = ft.rs_rounds > 0 ? 2 : ft.walk;
+    // (matrix-pipe segments: where the segmented walk would run at two waves per SIMD or fewer -- there a
+    // wave's walk is a chain of LDS round trips nobody hides; PDS_STFT_WALK=mseg: wherever built)
+    if (ft.walk == 1 && ft.ms_rounds > 0 && N >= PDS_MSEG_MIN_N && !force) ft.walk = 3;
+    if (force && std::strcmp(force, "mseg") == 0 && ft.ms_rounds > 0) ft.walk = 3;
     if (std::getenv("PDS_DEBUG_PLAN"))
       std::fprintf(stderr,
                    "pds plan N=%d filters=%d: ell slots %d reads %ld | seg rounds %d len %d reads %ld | rseg rounds %d "
-                   "len %d reads %ld cost %ld -> walk %d\n",
+                   "len %d reads %ld cost %ld | mseg rounds %d len %d reads %ld -> walk %d\n",
                    N, d.num_filts, ft.ell_slots, ft.ell_reads, ft.seg_rounds, ft.seg_len, ft.seg_reads, ft.rs_rounds,
-                   ft.rs_len, ft.rs_reads, ft.rs_cost, ft.walk);
+                   ft.rs_len, ft.rs_reads, ft.rs_cost, ft.ms_rounds, ft.ms_len, ft.ms_reads, ft.walk);
   }
   if (rc == PDS_OK) rc = upload(&ft.d_ell_w, ell_w.data(), ell_w.size());
   if (rc == PDS_OK) rc = upload(&ft.d_ell_meta, ell_meta.data(), ell_meta.size());
@@ -1978,6 +2100,8 @@ void fast_tables_destroy(pds_stft_plan *plan) {
   (void)hipFree(ft.d_tw_special);
   (void)hipFree(ft.d_mf_tab);
   (void)hipFree(ft.d_rs_w);
+  (void)hipFree(ft.d_ms_w);
+  (void)hipFree(ft.d_ms_meta);
   (void)hipFree(ft.d_rsn_w);
   (void)hipFree(ft.d_rsn_meta);
   (void)hipFree(ft.d_rs_meta);

@@ -540,11 +540,12 @@ def test_segmented_and_ell_filter_walks_agree(bank, monkeypatch):
 
 
 @pytest.mark.parametrize("switch,value", [("PDS_STFT_FRONT", "mfma"), ("PDS_STFT_WALK", "ell"), ("PDS_STFT_WALK", "seg"),
-                                          ("PDS_STFT_WALK", "rseg")])
-@pytest.mark.parametrize("name", ["c1_readme_fbank", "c2_tri_mel40", "c3_fbank80_energy", "c4_gabor64"])
+                                          ("PDS_STFT_WALK", "rseg"), ("PDS_STFT_WALK", "mseg")])
+@pytest.mark.parametrize("name", ["c1_readme_fbank", "c2_tri_mel40", "c3_fbank80_energy", "c4_gabor64",
+                                  "c5_gammatone64_48k"])
 def test_alternative_kernel_forms_match_the_oracle(switch, value, name, golden_meta, golden_tables, master_signal,
                                                    monkeypatch):
-    """The forms a plan does not pick by default -- matrix-pipe front end, each of the three filter walks --
+    """The forms a plan does not pick by default -- matrix-pipe front end, each of the four filter walks --
     through the same ragged batch (switches are read when the plan is
     created, so the computer is built after the switch is set)"""
     monkeypatch.setenv(switch, value)
