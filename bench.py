@@ -302,9 +302,7 @@ def main():
     comp = alias_factory_subclass_from_arg(ps.compute.FrameComputer, cfg)
 
     is_si = isinstance(comp, ps.si.ShortIntegrationFrameComputer)
-    cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline and not is_si:
-        cpu = cpu_baseline(comp, n)  # before the GPU is touched by this process
+    cpu = None  # (the CPU-baseline leg runs AFTER the timed region, see below)
 
     import torch
     import torch.distributed as dist
@@ -441,6 +439,14 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     finite = bool(torch.isfinite(out).all().item())
+    # The CPU-baseline leg (one spawned worker per host core for ~15 s) comes after the timed region: run in
+    # front of it, the GPU steps that followed were paced by a host still busy winding the workers down --
+    # 0.308 ms per step against 0.269 ms for the same kernel (rocprofv3 kernel trace, profiles/r2d_*), i.e.
+    # the line under-reported the GPU by 13 %.  Workers are spawned, not forked, so HIP being initialised in
+    # this process does not matter to them.
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and not is_si:
+        torch.cuda.synchronize(dev)
+        cpu = cpu_baseline(comp, n)
     spot = None
     if rank == 0 and not is_si:
         spot = parity_spot_check(comp, signal, offsets, lengths, layout, out, num_deltas=2 if deltas is not None else 0)

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Profiling recipe used for the summaries in this directory (run on the GPU box via gpurun):
-#   bash profiles/run_profile.sh <tag>
+#   [BENCH_ARGS="--workload <name>"] bash profiles/run_profile.sh <tag>
 # Pass 1: kernel trace + stats.  Passes 2..: PMC counters, one group per pass, never
 # combined with other trace domains.
 set -e
@@ -9,7 +9,7 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-BENCH="python3 $ROOT/bench.py --no-cpu-baseline"   # defaults: clock pre-roll, 10 warm-up, 100 timed steps
+BENCH="python3 $ROOT/bench.py --no-cpu-baseline ${BENCH_ARGS}"   # defaults: clock pre-roll, 10 warm-up, 100 timed steps; BENCH_ARGS="--workload ..." for another workload
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o stats -- $BENCH > $OUT/stats.log 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o pmc -- $BENCH > $OUT/pmc_fetch.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o pmc -- $BENCH > $OUT/pmc_write.log 2>&1

@@ -115,6 +115,9 @@ extern "C" __attribute__((visibility("default"))) void pds_debug_set_stamp_buffe
 #ifndef PDS_MSEG_MIN_N
 #define PDS_MSEG_MIN_N 1024
 #endif
+#ifndef PDS_MSEG_RED4  // (experiment: the partial sums of the matrix-pipe walk read four at a time)
+#define PDS_MSEG_RED4 1
+#endif
 #ifndef PDS_FILTER_UNROLL
 #define PDS_FILTER_UNROLL 2
 #endif
@@ -1409,6 +1412,24 @@ __global__ __launch_bounds__(MAXWAVES * 64, MINW) void stft_wave_kernel(const Fa
           const int fm = fmeta[f];
           const float4 *src = part + (fm & 0xffff);
           float4 sum = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+          if constexpr (SEG == 2 && PDS_MSEG_RED4) {
+            // (wide quads have up to ten partial sums: four reads in flight per pass instead of a round
+            // trip per partial; reads past the filter's last partial re-read it and are masked out)
+            const int cnt = fm >> 16;
+            for (int k = 0; k < cnt; k += 4) {
+              float4 v[4];
+#pragma unroll
+              for (int u = 0; u < 4; ++u) v[u] = src[PSTEP * (k + u < cnt ? k + u : cnt - 1)];
+#pragma unroll
+              for (int u = 0; u < 4; ++u) {
+                const bool live = k + u < cnt;
+                sum.x += live ? v[u].x : 0.0f;
+                sum.y += live ? v[u].y : 0.0f;
+                sum.z += live ? v[u].z : 0.0f;
+                sum.w += live ? v[u].w : 0.0f;
+              }
+            }
+          } else
           for (int k = fm >> 16; k > 0; --k) {
             const float4 v = *src;
             src += PSTEP;
