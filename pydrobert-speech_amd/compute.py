@@ -420,14 +420,18 @@ class ShortTimeFourierTransformFrameComputer(LinearFilterBankFrameComputer):
         if layout.extent > signal.numel():
             raise ValueError("an utterance lies outside the signal buffer")
         f64in = signal.dtype == torch.float64 and config.FLOAT64_ARITHMETIC == "float32" and not generic
-        if f64in and not plan.has_f64in:
-            # opt-in float32 arithmetic for float64 data at a transform size without a fused
-            # float64-input kernel: round the samples first
+
+        def rounded_first():
+            # opt-in float32 arithmetic for float64 data where no fused float64-input kernel serves the
+            # call (transform size without one, or a filter table too large for LDS): round the samples first
             feats = self.launch(signal.to(torch.float32), layout, pad_left=pad_left, preemphasis=preemphasis)
             if out is None:
                 return feats.to(torch.float64)
             out[: feats.shape[0], : feats.shape[1]] = feats
             return out
+
+        if f64in and not plan.has_f64in:
+            return rounded_first()
         if f64in and preemphasis and (out is None or out.dtype == torch.float64):
             # (float64 features with fused pre-emphasis: float32 features from the same kernel, widened)
             feats = self.launch(signal, layout, pad_left=pad_left, preemphasis=preemphasis,
@@ -487,6 +491,8 @@ class ShortTimeFourierTransformFrameComputer(LinearFilterBankFrameComputer):
                     out.stride(0),
                     stream,
                 )
+                if rc != 0 and f64in and lo == 0:
+                    return rounded_first()  # (e.g. the bank's table does not fit in LDS beside the waves' areas)
                 _native.check(rc, "pds_stft_batch")
         return out
 

@@ -183,6 +183,54 @@ def main():
                     print("FAIL", kind, "len", n, msg, json.dumps(cfg))
                     break
             if cfg["name"] == "stft" and comp.kernel_kind and kind.startswith("fused"):
+                # the one-launch statics + deltas form where the plan has it: the whole ragged batch, statics
+                # against the plain launch (same walk: bit for bit; else the walks' summation orders apart),
+                # deltas against the oracle's Deltas of the launch's own statics (float32 accumulation)
+                plan = comp._native_plan(torch.device("cuda", 0))
+                if plan.has_fused_deltas and bool(comp._log):
+                    from pydrobert_speech_amd.post import Deltas
+
+                    K = int(rng.integers(1, 3))
+                    xs = torch.from_numpy(np.concatenate(sigs)).cuda()
+                    offs = np.concatenate([[0], np.cumsum(lens)[:-1]])
+                    layout = comp.prepare_layout(offs, lens, device=xs.device)
+                    C = comp.num_coeffs
+                    out = torch.full((layout.total_rows, (K + 1) * C), float("nan"), device="cuda")
+                    comp.launch_with_deltas(xs, layout, Deltas(K), out=out, fused=True)
+                    mine = out.cpu().numpy()
+                    kinds["fused-deltas"] = kinds.get("fused-deltas", 0) + 1
+                    rows = layout.row_offsets
+                    for b in range(len(lens)):
+                        blk = mine[rows[b] : rows[b + 1]]
+                        ok, msg = close(blk[:, :C], want[b], is_log=True, **tol)
+                        if ok and blk.shape[0]:
+                            ref = orc.deltas(blk[:, :C], axis=0, num_deltas=K, target_axis=-1)
+                            scale = max(1.0, float(np.abs(blk[:, :C]).max()))
+                            err = np.abs(blk[:, C:].astype(np.float64) - ref[:, C:])
+                            ok = bool(np.isfinite(blk).all()) and float(err.max()) <= 4e-6 * scale
+                            msg = f"deltas err {err.max():.3g} scale {scale:.3g}"
+                        if not ok:
+                            fails += 1
+                            print("FAIL fused-deltas", "len", lens[b], msg, json.dumps(cfg))
+                            break
+                # float64 samples into the fused kernel (rounded at the frame load; 16-lane geometries: pair loads)
+                if plan.has_f64in and rng.random() < 0.5:
+                    xs = torch.from_numpy(np.concatenate(sigs).astype("f8")).cuda()
+                    offs = np.concatenate([[0], np.cumsum(lens)[:-1]])
+                    prev = ps.config.FLOAT64_ARITHMETIC
+                    ps.config.FLOAT64_ARITHMETIC = "float32"
+                    try:
+                        y64, rows64 = comp.compute_packed(xs, offs, lens)
+                    finally:
+                        ps.config.FLOAT64_ARITHMETIC = prev
+                    y64 = y64.cpu().numpy()
+                    kinds["f64in"] = kinds.get("f64in", 0) + 1
+                    for b in range(len(lens)):
+                        ok, msg = close(y64[rows64[b] : rows64[b + 1]], want[b], is_log=bool(comp._log), **tol)
+                        if not ok:
+                            fails += 1
+                            print("FAIL f64in", "len", lens[b], msg, json.dumps(cfg))
+                            break
                 x = torch.from_numpy(sigs[6]).cuda()
                 y, _ = comp.compute_packed(x, [0], [lens[6]], generic=True)
                 ok, msg = close(y.cpu().numpy(), want[6], is_log=bool(comp._log), **tol)
