@@ -115,6 +115,12 @@ extern "C" __attribute__((visibility("default"))) void pds_debug_set_stamp_buffe
 #ifndef PDS_MSEG_MIN_N
 #define PDS_MSEG_MIN_N 1024
 #endif
+#ifndef PDS_PAIR_SPLIT  // (N = 4096: a column's 64-point transform over a lane pair; 0: the lower half of the wave alone)
+#define PDS_PAIR_SPLIT 1
+#endif
+#ifndef PDS_N4096_MINW  // (waves per SIMD the 38-row N = 4096 instantiation is built for: with the pair split it needs 270 registers, i.e. 15 spilled dwords at two waves per SIMD, measured +19 % over one)
+#define PDS_N4096_MINW 2
+#endif
 #ifndef PDS_MSEG_RED4  // (experiment: the partial sums of the matrix-pipe walk read four at a time)
 #define PDS_MSEG_RED4 1
 #endif
@@ -912,6 +918,65 @@ __global__ __launch_bounds__(MAXWAVES * 64, MINW) void stft_wave_kernel(const Fa
 
     float pw[G::CPL][N2 + 1];
     float sp0 = 0.0f, sp1 = 0.0f;  // the two special bins of lane r <= N2/2
+    // PSPLIT (N = 4096 = 64 x 64, one frame per wave): the 32 columns would occupy half the wave and each
+    // lane a 64-point transform (256 registers of data).  Instead a column is shared by the lane PAIR
+    // (c, c + 32): the lower lane transforms the even-numbered column elements, the upper lane the odd ones
+    // (32 points each), `v_permlane32_swap` hands each lane one half of the other's outputs, and the lane
+    // finishes the radix-2 step for 16 values of k: Y[k'] = A + W_64^k' B and Y[k' + 32] = A - W_64^k' B,
+    // k' = k + 16 h.  Every lane works in this phase, on half the data.
+    constexpr bool PSPLIT = N2 == 64 && PDS_PAIR_SPLIT;
+    [[maybe_unused]] const int ph = lane >> 5, pc = lane & 31;
+    if constexpr (PSPLIT) {
+      static_assert(!PSPLIT || (G::CPL == 1 && COLS == 32 && G::GROUPS == 1), "pair split: 64 x 64");
+      const float4 *row = reinterpret_cast<const float4 *>(exch + pc * RS);
+      float zr[32], zi[32], Hr[32], Hi[32];
+#pragma unroll
+      for (int j = 0; j < 32; ++j) {
+        const float4 v = row[j];  // elements 2 j and 2 j + 1 of the column
+        zr[j] = ph ? v.z : v.x;
+        zi[j] = ph ? v.w : v.y;
+      }
+      PDS_PHASE(5);
+      inl::CFFT<32, 1>::run(zr, zi, Hr, Hi);  // A (lower lane) or B (upper lane)
+      PDS_PHASE(2);
+      inl::static_for<0, 16>([&](auto k_) {
+        constexpr int k = decltype(k_)::value;
+        // (first' = first.lo | second.lo, second' = first.hi | second.hi): lower lane A[k], B[k]; upper lane
+        // A[k + 16], B[k + 16]
+        const auto sr_ = __builtin_amdgcn_permlane32_swap(__float_as_uint(Hr[k]), __float_as_uint(Hr[k + 16]), false, false);
+        const auto si_ = __builtin_amdgcn_permlane32_swap(__float_as_uint(Hi[k]), __float_as_uint(Hi[k + 16]), false, false);
+        const float ar = __uint_as_float(sr_[0]), br = __uint_as_float(sr_[1]);
+        const float ai = __uint_as_float(si_[0]), bi = __uint_as_float(si_[1]);
+        // t = W_64^(k + 16 h) B = (-i)^h (W_64^k B)
+        float ur, ui;
+        inl::mul_tw<64, k>(br, bi, ur, ui);
+        const float tr = ph ? ui : ur, ti = ph ? -ur : ui;
+        const float yar = ar + tr, yai = ai + ti, ybr = ar - tr, ybi = ai - ti;
+        pw[0][k] = yar * yar + yai * yai;            // k2 = k + 16 h
+        pw[0][16 + k] = ybr * ybr + ybi * ybi;       // k2 = k + 16 h + 32
+        if (pc == 0) {
+          // the packed real column (lanes 0 and 32): its outputs go to row 0 of the exchange block for the
+          // lanes that untangle one bin pair each (both lanes are past reading the row)
+          exch[k + 16 * ph] = make_float2(yar, yai);
+          exch[k + 16 * ph + 32] = make_float2(ybr, ybi);
+        }
+      });
+#pragma unroll
+      for (int k2 = 32; k2 <= N2; ++k2) pw[0][k2] = 0.0f;
+      wave_sync();
+      {
+        const float2 ya = exch[r], yb = exch[(N2 - r) & (N2 - 1)];
+        const float ar = ya.x, ai = ya.y, br = yb.x, bi = yb.y;
+        const float sr = ar + br, si = ai - bi;
+        const float dr = ar - br, di = ai + bi;
+        const float tr = sw.x * di + sw.y * dr;
+        const float ti = sw.y * di - sw.x * dr;
+        const float xr = sr + tr, xi = si + ti;  // 2 X[m]
+        const float yr = sr - tr, yi = ti - si;  // 2 X[N2 - m]
+        sp0 = 0.25f * (xr * xr + xi * xi);
+        sp1 = 0.25f * (yr * yr + yi * yi);
+      }
+    } else
 #pragma unroll
     for (int q = 0; q < G::CPL; ++q) {
       const int kk = q * N2 + r;
@@ -1022,6 +1087,15 @@ __global__ __launch_bounds__(MAXWAVES * 64, MINW) void stft_wave_kernel(const Fa
     float *const Pw = RSG ? wbase + g : Pg;           // the lane's frame
     constexpr int PB = RSG ? 4 : 1;                   // floats per bin step
     constexpr int PDUMP = RSG ? NBP : PSTR - 1;       // bin index of the padding slot
+    if constexpr (PSPLIT) {
+      // the lane's 32 bins: pc + 64 k2 for k2 = k + 16 h, and the mirror images 4096 - pc - 64 (k2 + 32)
+      const int lo_bin = pc + 1024 * ph, hi_bin = 2048 - pc - 1024 * ph;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) {
+        Pw[(lo_bin + 64 * k) * PB] = pw[0][k];
+        Pw[(hi_bin - 64 * k) * PB] = pw[0][16 + k];
+      }
+    } else
 #pragma unroll
     for (int q = 0; q < G::CPL; ++q) {
       const int kk = q * N2 + r;
@@ -1793,7 +1867,7 @@ int32_t launch_stft_fast_f32(const pds_stft_plan *plan, const BatchArgs &a) {
       PDS_GEOM_ROWS(64, 32, 64, 2)
       break;
     case 4096:  // one frame per wavefront, one wavefront per SIMD (512 registers)
-      PDS_GEOM_ROWS(64, 64, 38, 1) PDS_GEOM_ROWS(64, 64, 48, 1) PDS_GEOM_ROWS(64, 64, 64, 1)
+      PDS_GEOM_ROWS(64, 64, 38, PDS_N4096_MINW) PDS_GEOM_ROWS(64, 64, 48, 1) PDS_GEOM_ROWS(64, 64, 64, 1)
       break;
     case 160: PDS_GEOM_ROWS(20, 8, 20, 4) break;
     case 200: PDS_GEOM_ROWS(25, 8, 25, 4) break;
