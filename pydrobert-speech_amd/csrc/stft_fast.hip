@@ -1350,7 +1350,8 @@ __global__ __launch_bounds__(MAXWAVES * 64, MINW) void stft_wave_kernel(const Fa
       continue;
     }
     if constexpr (SEG) {
-      static_assert(!SEG || (G::GROUPS == 4 && ELL_LDS), "segmented walk: four frames per wave, tables in LDS");
+      static_assert(!SEG || ELL_LDS, "segmented walks: tables in LDS");
+      static_assert(SEG != 2 || G::GROUPS == 4, "matrix-pipe segment walk: four frames per wave");
       {
         // Segmented walk for dense banks.  The rows of all filters are cut into segments of
         // seg_len bins and dealt to the 64 lanes, seg_rounds segments each; a lane reads a
@@ -1449,34 +1450,32 @@ __global__ __launch_bounds__(MAXWAVES * 64, MINW) void stft_wave_kernel(const Fa
           const int slot = q * 64 + lane;
           const int first = meta_lds[slot];
           const float4 *wrow = reinterpret_cast<const float4 *>(ellw_lds + __mul24(slot, p.seg_len + 4));
-          const float4 *p0 = reinterpret_cast<const float4 *>(wbase + first);
-          const float4 *p1 = reinterpret_cast<const float4 *>(wbase + PSTR + first);
-          const float4 *p2 = reinterpret_cast<const float4 *>(wbase + 2 * PSTR + first);
-          const float4 *p3 = reinterpret_cast<const float4 *>(wbase + 3 * PSTR + first);
-          float4 acc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+          const float4 *pg[G::GROUPS];
+          float acc[G::GROUPS];
+#pragma unroll
+          for (int gg = 0; gg < G::GROUPS; ++gg) {
+            pg[gg] = reinterpret_cast<const float4 *>(wbase + gg * PSTR + first);
+            acc[gg] = 0.0f;
+          }
           // (geometries with the 256-register budget keep twice as many reads in flight)
 #pragma unroll SEG_DEPTH
           for (int i = 0; i < steps; ++i) {
             const float4 w = wrow[i];
-            const float4 x0 = p0[i], x1 = p1[i], x2 = p2[i], x3 = p3[i];
-            acc.x = fmaf(w.x, x0.x, acc.x);
-            acc.y = fmaf(w.x, x1.x, acc.y);
-            acc.z = fmaf(w.x, x2.x, acc.z);
-            acc.w = fmaf(w.x, x3.x, acc.w);
-            acc.x = fmaf(w.y, x0.y, acc.x);
-            acc.y = fmaf(w.y, x1.y, acc.y);
-            acc.z = fmaf(w.y, x2.y, acc.z);
-            acc.w = fmaf(w.y, x3.y, acc.w);
-            acc.x = fmaf(w.z, x0.z, acc.x);
-            acc.y = fmaf(w.z, x1.z, acc.y);
-            acc.z = fmaf(w.z, x2.z, acc.z);
-            acc.w = fmaf(w.z, x3.z, acc.w);
-            acc.x = fmaf(w.w, x0.w, acc.x);
-            acc.y = fmaf(w.w, x1.w, acc.y);
-            acc.z = fmaf(w.w, x2.w, acc.z);
-            acc.w = fmaf(w.w, x3.w, acc.w);
+            float4 x[G::GROUPS];
+#pragma unroll
+            for (int gg = 0; gg < G::GROUPS; ++gg) x[gg] = pg[gg][i];
+#pragma unroll
+            for (int gg = 0; gg < G::GROUPS; ++gg) acc[gg] = fmaf(w.x, x[gg].x, acc[gg]);
+#pragma unroll
+            for (int gg = 0; gg < G::GROUPS; ++gg) acc[gg] = fmaf(w.y, x[gg].y, acc[gg]);
+#pragma unroll
+            for (int gg = 0; gg < G::GROUPS; ++gg) acc[gg] = fmaf(w.z, x[gg].z, acc[gg]);
+#pragma unroll
+            for (int gg = 0; gg < G::GROUPS; ++gg) acc[gg] = fmaf(w.w, x[gg].w, acc[gg]);
           }
-          part[slot] = acc;
+          float *dst = reinterpret_cast<float *>(part) + slot * G::GROUPS;
+#pragma unroll
+          for (int gg = 0; gg < G::GROUPS; ++gg) dst[gg] = acc[gg];
         }
         if constexpr (PDS_STAMPS > 1) PDS_STAMP(4, 0);  // (diagnostic: the rounds go to slot 4, the sums and stores stay in 5)
         wave_sync();
@@ -1484,8 +1483,10 @@ __global__ __launch_bounds__(MAXWAVES * 64, MINW) void stft_wave_kernel(const Fa
         constexpr int PSTEP = SEG == 2 ? 4 : 1;  // a filter's partial sums: consecutive slots, or a quad apart
         for (int f = lane; f < p.num_filts; f += 64) {
           const int fm = fmeta[f];
-          const float4 *src = part + (fm & 0xffff);
-          float4 sum = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+          const float *src = reinterpret_cast<const float *>(part) + (fm & 0xffff) * G::GROUPS;
+          float sum[G::GROUPS];
+#pragma unroll
+          for (int gg = 0; gg < G::GROUPS; ++gg) sum[gg] = 0.0f;
           if constexpr (SEG == 2 && PDS_MSEG_RED4) {
             // (wide quads have up to ten partial sums: four reads in flight per pass instead of a round
             // trip per partial; reads past the filter's last partial re-read it and are masked out)
@@ -1493,29 +1494,26 @@ __global__ __launch_bounds__(MAXWAVES * 64, MINW) void stft_wave_kernel(const Fa
             for (int k = 0; k < cnt; k += 4) {
               float4 v[4];
 #pragma unroll
-              for (int u = 0; u < 4; ++u) v[u] = src[PSTEP * (k + u < cnt ? k + u : cnt - 1)];
+              for (int u = 0; u < 4; ++u)
+                v[u] = *reinterpret_cast<const float4 *>(src + 4 * PSTEP * (k + u < cnt ? k + u : cnt - 1));
 #pragma unroll
               for (int u = 0; u < 4; ++u) {
                 const bool live = k + u < cnt;
-                sum.x += live ? v[u].x : 0.0f;
-                sum.y += live ? v[u].y : 0.0f;
-                sum.z += live ? v[u].z : 0.0f;
-                sum.w += live ? v[u].w : 0.0f;
+                sum[0] += live ? v[u].x : 0.0f;
+                sum[1] += live ? v[u].y : 0.0f;
+                sum[2] += live ? v[u].z : 0.0f;
+                sum[3] += live ? v[u].w : 0.0f;
               }
             }
           } else
           for (int k = fm >> 16; k > 0; --k) {
-            const float4 v = *src;
-            src += PSTEP;
-            sum.x += v.x;
-            sum.y += v.y;
-            sum.z += v.z;
-            sum.w += v.w;
-          }
-          const float vals[4] = {sum.x, sum.y, sum.z, sum.w};
 #pragma unroll
-          for (int gg = 0; gg < 4; ++gg) {
-            float v = vals[gg];
+            for (int gg = 0; gg < G::GROUPS; ++gg) sum[gg] += src[gg];
+            src += PSTEP * G::GROUPS;
+          }
+#pragma unroll
+          for (int gg = 0; gg < G::GROUPS; ++gg) {
+            float v = sum[gg];
             // max(val, floor) as Python evaluates it: a NaN stays a NaN (compute.py:459)
             if (p.use_log) v = fast_log(p.log_floor > v ? p.log_floor : v);
             if (gg < frames_here) obase[(int64_t)gg * p.out_stride + col0 + f] = (TOUT)v;
@@ -1661,7 +1659,8 @@ static int32_t launch_wave(const pds_stft_plan *plan, const BatchArgs &a) {
   // (fused deltas exist for the row-segment walk only: take it whatever the plan prefers)
   const bool dl = a.dl_K > 0 && ft.rsn_rounds > 0;  // (its own table: numbered order)
   constexpr bool MSG = G::GROUPS == 4 && inl::is_pow2(N1);  // matrix-pipe segment walk instantiated
-  for (int cand = (G::GROUPS == 4) ? (dl ? 2 : ft.walk) : 0; cand >= 0 && !in_lds; --cand) {
+  constexpr bool SEGOK = G::GROUPS == 4 || (inl::is_pow2(N1) && N2 >= 32);  // segmented walk instantiated
+  for (int cand = (G::GROUPS == 4) ? (dl ? 2 : ft.walk) : (SEGOK && ft.walk == 1 ? 1 : 0); cand >= 0 && !in_lds; --cand) {
     if (cand == 3 && (!MSG || ft.ms_rounds == 0 || pre || a.in_f64)) continue;
     // (no segmented variant of the fused pre-emphasis kernel)
     if ((cand == 2 && !dl && ft.rs_rounds == 0) || (cand == 1 && (ft.seg_rounds == 0 || pre || a.in_f64))) continue;
@@ -1670,7 +1669,7 @@ static int32_t launch_wave(const pds_stft_plan *plan, const BatchArgs &a) {
     const size_t fixed = (size_t)N2 * 8 + (size_t)meta_pad * 4;
     const size_t table_bytes = (size_t)(cand == 3 ? ft.ms_wfloats : cand == 2 ? (dl ? ft.rsn_wfloats : ft.rs_wfloats) : cand == 1 ? ft.seg_wfloats : ft.ell_wfloats) * 4;
     // (segment sums live behind P in the wave's area)
-    if (cand == 1 && (size_t)G::GROUPS * G::PSTR * 4 + (size_t)ft.seg_rounds * 64 * 16 > per_wave) continue;
+    if (cand == 1 && (size_t)G::GROUPS * G::PSTR * 4 + (size_t)ft.seg_rounds * 64 * 4 * G::GROUPS > per_wave) continue;
     if (cand == 3 && (size_t)G::GROUPS * G::PSTR * 4 + (size_t)ft.ms_rounds * 64 * 16 > per_wave) continue;
     for (const auto &shape : shapes)
       if (shape[0] * per_wave + fixed + table_bytes <= lds_cu / shape[1]) {
@@ -1721,12 +1720,12 @@ static int32_t launch_wave(const pds_stft_plan *plan, const BatchArgs &a) {
 #endif
   const size_t smem = waves * per_wave + fixed + (in_lds ? table_bytes : 0);
   constexpr bool W4 = G::GROUPS == 4;  // the walks over four frames exist for the 16-lane geometries
-  const bool seg = W4 && (walk == 1 || walk == 3), rsg = W4 && walk == 2, mseg = MSG && walk == 3;
+  const bool seg = SEGOK && (walk == 1 || walk == 3), rsg = W4 && walk == 2, mseg = MSG && walk == 3;
   auto kern = pre      ? (rsg ? stft_wave_kernel<N1, N2, NROWS, CU_WAVES_K, MINW, true, true, false, 0, W4>
                               : stft_wave_kernel<N1, N2, NROWS, CU_WAVES_K, MINW, true, true>)
               : rsg    ? stft_wave_kernel<N1, N2, NROWS, CU_WAVES_K, MINW, true, false, false, 0, W4>
               : mseg   ? stft_wave_kernel<N1, N2, NROWS, CU_WAVES_K, MINW, true, false, MSG ? 2 : 0>
-              : seg    ? stft_wave_kernel<N1, N2, NROWS, CU_WAVES_K, MINW, true, false, W4>
+              : seg    ? stft_wave_kernel<N1, N2, NROWS, CU_WAVES_K, MINW, true, false, SEGOK ? 1 : 0>
               : in_lds ? stft_wave_kernel<N1, N2, NROWS, CU_WAVES_K, MINW, true, false>
                        : stft_wave_kernel<N1, N2, NROWS, CU_WAVES_K, MINW, false, false>;
   // matrix-pipe front end: the 32 x 16 geometry with LDS-resident filter tables, when the plan has
@@ -2016,11 +2015,16 @@ int32_t fast_tables_create(pds_stft_plan *plan, const double *window, const int3
   // segments take consecutive slots, slot = round * 64 + lane.  It is used when it needs a fifth
   // fewer 16-byte LDS reads per item than the ELL walk (two per 4 bins of the longest row of
   // every slot there; five per 4 bins of a segment and FOUR frames here, plus the sums).
-  if (n2 == 16 && d.num_filts > 0 && d.num_filts <= 65535) {
+  // (Round 2: also for the power-of-two geometries with 32 and 64 lanes per frame, N = 2048 and 4096, two
+  // frames and one frame per wave: there the ELL walk's pace is set by its longest row -- the 213-bin top
+  // filter of an 80-filter mel bank at N = 4096 while the lanes of short filters idle -- and segments of
+  // equal length dealt to all 64 lanes need fewer reads in fewer dependent steps.)
+  const int groups = 64 / n2;  // frames per wave
+  if ((n2 == 16 || (pow2 && n2 >= 32)) && d.num_filts > 0 && d.num_filts <= 65535) {
     long ell_reads = 0;
-    for (int sl = 0; sl < slots; ++sl) ell_reads += 2L * (ell_len[sl] / 4);  // per item (the 64 lanes cover 4 frames)
+    for (int sl = 0; sl < slots; ++sl) ell_reads += 2L * (ell_len[sl] / 4);  // per lane and item
     ft.ell_reads = ell_reads;
-    const int free_slots = ((n1 / 2) * (n2 + 2) * 4 * 2 - 4 * pstr) / 4;  // float4 slots behind P
+    const int free_slots = (groups * cols * (n2 + 2) * 2 - groups * pstr) / groups;  // partial slots behind P
     int best_len = 0, best_rounds = 0;
     long best_reads = 0;
     for (int len : {16, 32, 64}) {
@@ -2028,15 +2032,20 @@ int32_t fast_tables_create(pds_stft_plan *plan, const double *window, const int3
       for (int f = 0; f < d.num_filts; ++f) nseg += (span(f) + len - 1) / len;
       const int rounds = (int)((nseg + 63) / 64);
       if (rounds == 0 || rounds * 64 > free_slots || rounds * 64 > 65535) continue;
-      const long reads = (long)rounds * (len / 4) * 5 + rounds + (nseg + 63) / 64 + 4;
+      const long reads = (long)rounds * (len / 4) * (1 + groups) + rounds + (nseg + 63) / 64 + 4;
       if (!best_len || reads < best_reads) best_len = len, best_rounds = rounds, best_reads = reads;
     }
     const char *force = std::getenv("PDS_STFT_SEGMENTED");  // "1": whenever feasible, "0": never
+    if (!force && std::getenv("PDS_STFT_WALK") && std::strcmp(std::getenv("PDS_STFT_WALK"), "seg") == 0) force = "1";
     // (measured: Gammatone-64 at N = 1024, 180 reads against 375: +3.5 %; Gabor-64 at N = 512, 48 against
     // 64: +5 %; the 40-filter mel bank, 26 against 32: -0.5 %; 80 mel filters, more reads: -2 %)
     // with four and more ELL slots their per-slot epilogues (log, scattered stores) weigh in as well
-    const bool want = force ? force[0] == '1'
-                            : 5 * best_reads <= 4 * ell_reads || (slots >= 4 && best_reads < ell_reads);
+    // (80 mel filters at 48 kHz: N = 4096, one frame per wave, 54 reads against 96: +18 %; N = 2048, two frames
+    // per wave, 46 against 60: -6 %, so the 32-lane geometries take it only when forced)
+    const bool want = force    ? force[0] == '1'
+                      : n2 == 64 ? best_reads < ell_reads
+                      : n2 == 32 ? false
+                                 : 5 * best_reads <= 4 * ell_reads || (slots >= 4 && best_reads < ell_reads);
     if (best_len && want) {
       const int len = best_len, nslots = best_rounds * 64, wstride = len + 4;
       std::vector<float> seg_w((size_t)nslots * wstride, 0.0f);

@@ -1,0 +1,6 @@
+set -e
+timeout -k 10 900 python -m pytest tests -x -q -m gpu > gpurun_out/t_all.log 2>&1 || { tail -40 gpurun_out/t_all.log; exit 1; }
+tail -1 gpurun_out/t_all.log
+timeout -k 10 900 python tools/fuzz_parity.py 500 2718 > gpurun_out/fuzz_r2g.log 2>&1 || { tail -20 gpurun_out/fuzz_r2g.log | cut -c1-600; exit 1; }
+tail -1 gpurun_out/fuzz_r2g.log | cut -c1-200
+bash tools/bench_all.sh > gpurun_out/bench_all_r2f.txt 2>&1; cat gpurun_out/bench_all_r2f.txt
