@@ -1487,22 +1487,31 @@ __global__ __launch_bounds__(MAXWAVES * 64, MINW) void stft_wave_kernel(const Fa
           float sum[G::GROUPS];
 #pragma unroll
           for (int gg = 0; gg < G::GROUPS; ++gg) sum[gg] = 0.0f;
-          if constexpr (SEG == 2 && PDS_MSEG_RED4) {
-            // (wide quads have up to ten partial sums: four reads in flight per pass instead of a round
+          if constexpr (PDS_MSEG_RED4) {
+            // (long rows have ten and more partial sums: four reads in flight per pass instead of a round
             // trip per partial; reads past the filter's last partial re-read it and are masked out)
             const int cnt = fm >> 16;
             for (int k = 0; k < cnt; k += 4) {
-              float4 v[4];
+              float v[4][G::GROUPS];
 #pragma unroll
-              for (int u = 0; u < 4; ++u)
-                v[u] = *reinterpret_cast<const float4 *>(src + 4 * PSTEP * (k + u < cnt ? k + u : cnt - 1));
+              for (int u = 0; u < 4; ++u) {
+                const float *at = src + G::GROUPS * PSTEP * (k + u < cnt ? k + u : cnt - 1);
+                if constexpr (G::GROUPS == 4) {
+                  const float4 t = *reinterpret_cast<const float4 *>(at);
+                  v[u][0] = t.x, v[u][1] = t.y, v[u][2] = t.z, v[u][3] = t.w;
+                } else if constexpr (G::GROUPS == 2) {
+                  const float2 t = *reinterpret_cast<const float2 *>(at);
+                  v[u][0] = t.x, v[u][1] = t.y;
+                } else {
+#pragma unroll
+                  for (int gg = 0; gg < G::GROUPS; ++gg) v[u][gg] = at[gg];
+                }
+              }
 #pragma unroll
               for (int u = 0; u < 4; ++u) {
                 const bool live = k + u < cnt;
-                sum[0] += live ? v[u].x : 0.0f;
-                sum[1] += live ? v[u].y : 0.0f;
-                sum[2] += live ? v[u].z : 0.0f;
-                sum[3] += live ? v[u].w : 0.0f;
+#pragma unroll
+                for (int gg = 0; gg < G::GROUPS; ++gg) sum[gg] += live ? v[u][gg] : 0.0f;
               }
             }
           } else
@@ -2027,12 +2036,17 @@ int32_t fast_tables_create(pds_stft_plan *plan, const double *window, const int3
     const int free_slots = (groups * cols * (n2 + 2) * 2 - groups * pstr) / groups;  // partial slots behind P
     int best_len = 0, best_rounds = 0;
     long best_reads = 0;
+    const char *only_len = std::getenv("PDS_SEG_LEN");  // (measurement: one segment length)
     for (int len : {16, 32, 64}) {
+      if (only_len && std::atoi(only_len) != len) continue;
       long nseg = 0;
       for (int f = 0; f < d.num_filts; ++f) nseg += (span(f) + len - 1) / len;
       const int rounds = (int)((nseg + 63) / 64);
       if (rounds == 0 || rounds * 64 > free_slots || rounds * 64 > 65535) continue;
-      const long reads = (long)rounds * (len / 4) * (1 + groups) + rounds + (nseg + 63) / 64 + 4;
+      int longest = 0;
+      for (int f = 0; f < d.num_filts; ++f) longest = std::max(longest, (span(f) + len - 1) / len);
+      // (reads of the rounds, their epilogues, and the partial sums a filter's lane adds up four at a time)
+      const long reads = (long)rounds * (len / 4) * (1 + groups) + rounds + (nseg + 63) / 64 + 4 + 4L * ((longest + 3) / 4);
       if (!best_len || reads < best_reads) best_len = len, best_rounds = rounds, best_reads = reads;
     }
     const char *force = std::getenv("PDS_STFT_SEGMENTED");  // "1": whenever feasible, "0": never
