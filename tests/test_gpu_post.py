@@ -374,7 +374,7 @@ def test_deltas_pad_modes_match_reference_outputs(name, kwargs):
 
 
 @pytest.mark.parametrize("K", [1, 2])
-@pytest.mark.parametrize("bank", ["fbank80_energy", "mel40", "mel64_1024_energy"])
+@pytest.mark.parametrize("bank", ["fbank80_energy", "mel40", "mel64_1024_energy", "mel96_energy", "mel26_energy"])
 def test_fused_statics_and_deltas_launch(K, bank):
     """pds_stft_deltas_batch_f32 (one launch: every wave walks a stretch of frames and differentiates them
     from the coefficients in its registers) against the two launches, on a ragged batch with empty,
@@ -393,6 +393,11 @@ def test_fused_statics_and_deltas_launch(K, bank):
         "mel64_1024_energy": {"name": "stft", "bank": {"name": "tri", "scaling_function": "mel", "num_filts": 64,
                                                        "sampling_rate": 48000},
                               "frame_length_ms": 20, "include_energy": True, "use_power": True},
+        # rows wider than 64 lanes x 16 bytes (97 coefficients: 291 columns), and a row width of 4 n + 1 (27: 81)
+        "mel96_energy": {"name": "stft", "bank": {"name": "fbank", "num_filts": 96}, "frame_length_ms": 25,
+                         "include_energy": True, "use_power": True},
+        "mel26_energy": {"name": "stft", "bank": {"name": "fbank", "num_filts": 26}, "frame_length_ms": 25,
+                         "include_energy": True, "use_power": True},
     }[bank]
     comp = alias_factory_subclass_from_arg(FrameComputer, cfg)
     assert comp._native_plan().has_fused_deltas
@@ -413,8 +418,8 @@ def test_fused_statics_and_deltas_launch(K, bank):
         deltas.apply_rows(two[:, :C], layout.row_offsets, out=two)
         scale = float(two[:, :C].abs().max()) if layout.total_rows else 1.0
         # (the same kernel code computes the statics: bit for bit when the plain launch takes the
-        # row-segment walk too, else the two walks' summation orders apart)
-        same_walk = bank != "mel64_1024_energy"
+        # row-segment walk with the same segment length too, else the two walks' summation orders apart)
+        same_walk = bank in ("fbank80_energy", "mel40")
         assert torch.equal(fused[:, :C], two[:, :C]) or (
             not same_walk and float((fused[:, :C] - two[:, :C]).abs().max()) <= 2e-6 * scale), what
         err = (fused[:, C:] - two[:, C:]).abs()
