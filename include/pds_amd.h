@@ -135,6 +135,17 @@ int32_t pds_stft_batch_f64in(const pds_stft_plan *plan, const double *d_signal,
                              const int64_t *d_nframes, const int64_t *d_row_off, int32_t B,
                              int64_t max_frames, int32_t pad_left, double preemph, void *d_out,
                              int32_t out_is_f64, int64_t out_stride, void *stream);
+/* pds_stft_batch_f32 for RAGGED batches: the same kernels, but every wave walks one contiguous stretch of the
+ * chunks that exist (the utterances' chunk counts are summed into `d_workspace`, B + 1 int64 on the device, by
+ * a small kernel in front) instead of the waves being dealt (utterance, chunk < chunks of the longest) pairs of
+ * which short utterances have none: lengths uniform in 1 ... 15 s run 9 % slower per frame than equal lengths
+ * with the plain call, as fast with this one.  Same values bit for bit.  With fused pre-emphasis, or a plan
+ * without a fused kernel, it is the plain call. */
+int32_t pds_stft_batch_ragged_f32(const pds_stft_plan *plan, const float *d_signal,
+                                  const int64_t *d_offsets, const int64_t *d_lengths,
+                                  const int64_t *d_nframes, const int64_t *d_row_off, int32_t B,
+                                  int64_t max_frames, int32_t pad_left, double preemph,
+                                  int64_t *d_workspace, float *d_out, int64_t out_stride, void *stream);
 /* Statics AND deltas in one launch (BASELINE.json configs[2]; reference post.py:462-491 applied to
  * compute_full's output along time, "edge" padding): row r of utterance b receives the num_coeffs
  * statics at columns [0, C) and the order-k deltas at [k C, (k + 1) C), k = 1 .. num_deltas.  The

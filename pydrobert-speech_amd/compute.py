@@ -171,6 +171,11 @@ class PackedLayout:
         self.nframes = nframes  # host int64[B]
         self.row_offsets = row_offsets  # host int64[B + 1]
         self.d_meta = d_meta  # device int64[4, B]: offsets, lengths, nframes, row offsets
+        # share of the (utterance, frame < longest) grid that exists: ragged batches (< 0.9) take the launch
+        # that deals the existing chunks evenly (pds_stft_batch_ragged_f32); its device workspace, on demand
+        top = int(nframes.max()) if B else 0
+        self.fill = float(nframes.sum()) / (top * B) if top else 1.0
+        self.d_work = None
 
     @property
     def total_rows(self) -> int:
@@ -453,6 +458,14 @@ class ShortTimeFourierTransformFrameComputer(LinearFilterBankFrameComputer):
                 return lib.pds_stft_batch_f64in(*args[:11], is64, *args[11:])
         elif signal.dtype == torch.float32:
             fn = lib.pds_stft_batch_f32_generic if generic else lib.pds_stft_batch_f32
+            if not generic and not preemphasis and plan.kernel_kind and layout.fill < 0.9 and config.RAGGED_SCHEDULING:
+                if layout.d_work is None or layout.d_work.device != signal.device:
+                    layout.d_work = torch.empty(min(layout.B, _MAX_UTTS_PER_CALL) + 1, dtype=torch.int64,
+                                                device=signal.device)
+                work = layout.d_work.data_ptr()
+
+                def fn(*args):
+                    return lib.pds_stft_batch_ragged_f32(*args[:10], work, *args[10:])
         elif signal.dtype == torch.float64:
             fn = lib.pds_stft_batch_f64
         else:

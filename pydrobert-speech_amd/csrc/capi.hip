@@ -207,6 +207,25 @@ int32_t pds_stft_plan_has_fused_deltas(const pds_stft_plan *plan) {
   return plan && pds::fast_has_fused_deltas(plan) ? 1 : 0;
 }
 
+int32_t pds_stft_batch_ragged_f32(const pds_stft_plan *plan, const float *d_signal, const int64_t *d_offsets,
+                                  const int64_t *d_lengths, const int64_t *d_nframes, const int64_t *d_row_off,
+                                  int32_t B, int64_t max_frames, int32_t pad_left, double preemph, int64_t *d_workspace,
+                                  float *d_out, int64_t out_stride, void *stream) {
+  int32_t rc = check_batch(plan, d_signal, d_offsets, d_lengths, d_nframes, d_row_off, B, max_frames, pad_left,
+                           d_out, out_stride);
+  if (rc == 1) return PDS_OK;
+  if (rc != PDS_OK) return rc;
+  if (!d_workspace) return invalid("stft_batch_ragged: null workspace (B + 1 int64 on the device)");
+  rc = pds::check_plan_device(plan->device, "stft_batch");
+  if (rc != PDS_OK) return rc;
+  pds::BatchArgs a{d_signal,   d_offsets, d_lengths,  d_nframes, d_row_off, B, max_frames,
+                   pad_left < 0 ? plan->d.pad_left : pad_left, preemph, d_out, out_stride, (hipStream_t)stream};
+  a.d_chunk_prefix = d_workspace;
+  a.stretch = true;
+  // (plans without a fused kernel take the generic one: its workgroups are frames, nothing to balance)
+  return plan->fast.kind ? pds::launch_stft_fast_f32(plan, a) : pds::launch_stft_generic_f32(plan, a);
+}
+
 int32_t pds_stft_deltas_batch_f32(const pds_stft_plan *plan, const float *d_signal, const int64_t *d_offsets,
                                   const int64_t *d_lengths, const int64_t *d_nframes, const int64_t *d_row_off,
                                   int32_t B, int64_t max_frames, int32_t pad_left, int32_t num_deltas,

@@ -129,6 +129,8 @@ struct BatchArgs {
   int dl_K = 0;
   double dl_taps[16] = {0};
   int64_t *d_chunk_prefix = nullptr;  // workspace of B + 1 entries (the utterances' chunk counts, summed)
+  // ragged batches (pds_stft_batch_ragged_f32): stretch scheduling over the existing chunks, needs the workspace
+  bool stretch = false;
 };
 
 // stft_generic.hip
