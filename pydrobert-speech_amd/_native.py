@@ -164,6 +164,13 @@ def lib() -> ctypes.CDLL:
                 f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; "
                 "g.build()'` or `make -C pydrobert-speech_amd/csrc` (there is no CPU fallback)"
             )
+        # torch's HIP runtime first where torch is installed: the library's own dependency on libamdhip64
+        # then resolves to the copy already in the process (loaded the other way round, the two runtimes
+        # disagree about the devices)
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         loaded = ctypes.CDLL(LIB_PATH)
         for name, (restype, argtypes) in SIGNATURES.items():
             fn = getattr(loaded, name)  # AttributeError if the .so is stale
