@@ -237,7 +237,7 @@ struct WaveGeom {
   static_assert(EXCH_F2 * 2 >= 64 * NROWS, "edge-frame gather reuses the exchange area");
   static_assert(N % 2 == 0 && CPL >= 1 && N2 <= 64 && (RS * 8) % 16 == 0, "geometry");
   // (N = 4096 = 64 x 64 has 32 columns for 64 lanes: the upper half of the wave idles in step 3)
-  static_assert(inl::is_pow2(N1) ? (FULL || N2 == 64) : 600 % N1 == 0,
+  static_assert(inl::is_pow2(N1) ? (FULL || N2 == 2 * COLS) : 600 % N1 == 0,
                 "in-lane DFT sizes: 2^k, or a divisor of 600");
   static_assert(NROWS <= N1 && NROWS > 0, "rows");
 };
@@ -956,45 +956,57 @@ __global__ __launch_bounds__(MAXWAVES * 64, MINW) void stft_wave_kernel(const Fa
     // (32 points each), `v_permlane32_swap` hands each lane one half of the other's outputs, and the lane
     // finishes the radix-2 step for 16 values of k: Y[k'] = A + W_64^k' B and Y[k' + 32] = A - W_64^k' B,
     // k' = k + 16 h.  Every lane works in this phase, on half the data.
-    constexpr bool PSPLIT = N2 == 64 && PDS_PAIR_SPLIT;
-    [[maybe_unused]] const int ph = lane >> 5, pc = lane & 31;
+    // (The same for 32 lanes per frame and 16 columns -- N = 1024 as 32 x 32, two frames per wave, lane pairs
+    // (c, c + 16) through v_permlane16_swap: the 64 x 16 form of that size holds a 64-point in-lane real
+    // transform, 256 registers and 18 KB of LDS per wave; this one 128 and 8.7.)
+    constexpr bool PSPLIT = PDS_PAIR_SPLIT && N2 == 2 * COLS && (N2 == 64 || N2 == 32);
+    constexpr int PH = N2 / 2, PQ = N2 / 4;  // points of a lane's transform, values of k it finishes
+    [[maybe_unused]] const int ph = r / (N2 / 2), pc = r % (N2 / 2);
     if constexpr (PSPLIT) {
-      static_assert(!PSPLIT || (G::CPL == 1 && COLS == 32 && G::GROUPS == 1), "pair split: 64 x 64");
+      static_assert(!PSPLIT || (G::CPL == 1 && COLS == PH), "pair split: the columns fill half the frame's lanes");
       const float4 *row = reinterpret_cast<const float4 *>(exch + pc * RS);
-      float zr[32], zi[32], Hr[32], Hi[32];
+      float zr[PH], zi[PH], Hr[PH], Hi[PH];
 #pragma unroll
-      for (int j = 0; j < 32; ++j) {
+      for (int j = 0; j < PH; ++j) {
         const float4 v = row[j];  // elements 2 j and 2 j + 1 of the column
         zr[j] = ph ? v.z : v.x;
         zi[j] = ph ? v.w : v.y;
       }
       PDS_PHASE(5);
-      inl::CFFT<32, 1>::run(zr, zi, Hr, Hi);  // A (lower lane) or B (upper lane)
+      inl::CFFT<PH, 1>::run(zr, zi, Hr, Hi);  // A (lower lane) or B (upper lane)
       PDS_PHASE(2);
-      inl::static_for<0, 16>([&](auto k_) {
+      inl::static_for<0, PQ>([&](auto k_) {
         constexpr int k = decltype(k_)::value;
-        // (first' = first.lo | second.lo, second' = first.hi | second.hi): lower lane A[k], B[k]; upper lane
-        // A[k + 16], B[k + 16]
-        const auto sr_ = __builtin_amdgcn_permlane32_swap(__float_as_uint(Hr[k]), __float_as_uint(Hr[k + 16]), false, false);
-        const auto si_ = __builtin_amdgcn_permlane32_swap(__float_as_uint(Hi[k]), __float_as_uint(Hi[k + 16]), false, false);
-        const float ar = __uint_as_float(sr_[0]), br = __uint_as_float(sr_[1]);
-        const float ai = __uint_as_float(si_[0]), bi = __uint_as_float(si_[1]);
-        // t = W_64^(k + 16 h) B = (-i)^h (W_64^k B)
+        // (first' = first.lo | second.lo, second' = first.hi | second.hi, lo / hi = the halves of a frame's lane
+        // group): lower lane A[k], B[k]; upper lane A[k + PQ], B[k + PQ]
+        float ar, br, ai, bi;
+        if constexpr (N2 == 64) {
+          const auto sr_ = __builtin_amdgcn_permlane32_swap(__float_as_uint(Hr[k]), __float_as_uint(Hr[k + PQ]), false, false);
+          const auto si_ = __builtin_amdgcn_permlane32_swap(__float_as_uint(Hi[k]), __float_as_uint(Hi[k + PQ]), false, false);
+          ar = __uint_as_float(sr_[0]), br = __uint_as_float(sr_[1]);
+          ai = __uint_as_float(si_[0]), bi = __uint_as_float(si_[1]);
+        } else {
+          const auto sr_ = __builtin_amdgcn_permlane16_swap(__float_as_uint(Hr[k]), __float_as_uint(Hr[k + PQ]), false, false);
+          const auto si_ = __builtin_amdgcn_permlane16_swap(__float_as_uint(Hi[k]), __float_as_uint(Hi[k + PQ]), false, false);
+          ar = __uint_as_float(sr_[0]), br = __uint_as_float(sr_[1]);
+          ai = __uint_as_float(si_[0]), bi = __uint_as_float(si_[1]);
+        }
+        // t = W_N2^(k + PQ h) B = (-i)^h (W_N2^k B)
         float ur, ui;
-        inl::mul_tw<64, k>(br, bi, ur, ui);
+        inl::mul_tw<N2, k>(br, bi, ur, ui);
         const float tr = ph ? ui : ur, ti = ph ? -ur : ui;
         const float yar = ar + tr, yai = ai + ti, ybr = ar - tr, ybi = ai - ti;
-        pw[0][k] = yar * yar + yai * yai;            // k2 = k + 16 h
-        pw[0][16 + k] = ybr * ybr + ybi * ybi;       // k2 = k + 16 h + 32
+        pw[0][k] = yar * yar + yai * yai;            // k2 = k + PQ h
+        pw[0][PQ + k] = ybr * ybr + ybi * ybi;       // k2 = k + PQ h + PH
         if (pc == 0) {
-          // the packed real column (lanes 0 and 32): its outputs go to row 0 of the exchange block for the
-          // lanes that untangle one bin pair each (both lanes are past reading the row)
-          exch[k + 16 * ph] = make_float2(yar, yai);
-          exch[k + 16 * ph + 32] = make_float2(ybr, ybi);
+          // the packed real column (the pair's two lanes): its outputs go to row 0 of the exchange block for
+          // the lanes that untangle one bin pair each (both lanes are past reading the row)
+          exch[k + PQ * ph] = make_float2(yar, yai);
+          exch[k + PQ * ph + PH] = make_float2(ybr, ybi);
         }
       });
 #pragma unroll
-      for (int k2 = 32; k2 <= N2; ++k2) pw[0][k2] = 0.0f;
+      for (int k2 = PH; k2 <= N2; ++k2) pw[0][k2] = 0.0f;
       wave_sync();
       {
         const float2 ya = exch[r], yb = exch[(N2 - r) & (N2 - 1)];
@@ -1120,12 +1132,12 @@ __global__ __launch_bounds__(MAXWAVES * 64, MINW) void stft_wave_kernel(const Fa
     constexpr int PB = RSG ? 4 : 1;                   // floats per bin step
     constexpr int PDUMP = RSG ? NBP : PSTR - 1;       // bin index of the padding slot
     if constexpr (PSPLIT) {
-      // the lane's 32 bins: pc + 64 k2 for k2 = k + 16 h, and the mirror images 4096 - pc - 64 (k2 + 32)
-      const int lo_bin = pc + 1024 * ph, hi_bin = 2048 - pc - 1024 * ph;
+      // the lane's bins: pc + N1 k2 for k2 = k + PQ h, and the mirror images N - pc - N1 (k2 + PH)
+      const int lo_bin = pc + N1 * PQ * ph, hi_bin = N / 2 - pc - N1 * PQ * ph;
 #pragma unroll
-      for (int k = 0; k < 16; ++k) {
-        Pw[(lo_bin + 64 * k) * PB] = pw[0][k];
-        Pw[(hi_bin - 64 * k) * PB] = pw[0][16 + k];
+      for (int k = 0; k < PQ; ++k) {
+        Pw[(lo_bin + N1 * k) * PB] = pw[0][k];
+        Pw[(hi_bin - N1 * k) * PB] = pw[0][PQ + k];
       }
     } else
 #pragma unroll
@@ -1912,6 +1924,12 @@ int32_t launch_stft_fast_f32(const pds_stft_plan *plan, const BatchArgs &a) {
       PDS_GEOM_ROWS(32, 16, 30, 4) PDS_GEOM_ROWS(32, 16, 32, 4)
       break;
     case 1024:
+      if (plan->fast.n2 == 32) {
+        // (three waves per SIMD: 168 registers -- at 128 the 30-row form spills 33 dwords -- and the dense banks this
+        // geometry is for leave room for twelve waves per CU beside their tables anyway)
+        PDS_GEOM_ROWS(32, 32, 24, 3) PDS_GEOM_ROWS(32, 32, 30, 3) PDS_GEOM_ROWS(32, 32, 32, 3)
+        break;
+      }
       PDS_GEOM_ROWS(64, 16, 40, 2) PDS_GEOM_ROWS(64, 16, 50, 2)
       PDS_GEOM_ROWS(64, 16, 60, 2) PDS_GEOM_ROWS(64, 16, 64, 2)
       break;
@@ -1950,7 +1968,20 @@ int32_t fast_tables_create(pds_stft_plan *plan, const double *window, const int3
     case 128: n1 = 16; n2 = 8; break;
     case 256: n1 = 32; n2 = 8; break;
     case 512: n1 = 32; n2 = 16; break;
-    case 1024: n1 = 64; n2 = 16; break;
+    case 1024: {
+      // 64 x 16 (four frames per wave, 64-point in-lane real transform: 256 registers, 18 KB of LDS per wave)
+      // or, with PDS_N1024_GEOM=32x32, 32 x 32 (two frames per wave, a column's transform over a lane pair:
+      // 168 registers, 8.7 KB).  The second form was built for the dense banks, whose tables leave the first
+      // one six waves per CU: it runs twelve, and measures the same (Gammatone-64 at 48 kHz: 0.339 against
+      // 0.335 ms per step) -- with two frames per wave its filter walk is the segmented one at three reads per
+      // four bins, 3300 cycles per frame against 1300 for the matrix-pipe walk over four frames, which eats
+      // what the transforms gain.  Opt-in.
+      const char *geom = std::getenv("PDS_N1024_GEOM");
+      const bool wide = geom && std::strcmp(geom, "32x32") == 0;
+      n1 = wide ? 32 : 64;
+      n2 = wide ? 32 : 16;
+      break;
+    }
     case 2048: n1 = 64; n2 = 32; break;
     case 4096: n1 = 64; n2 = 64; break;
     case 160: n1 = 20; n2 = 8; break;
@@ -2103,7 +2134,7 @@ int32_t fast_tables_create(pds_stft_plan *plan, const double *window, const int3
     // per wave, 46 against 60: -6 %, so the 32-lane geometries take it only when forced)
     const bool want = force    ? force[0] == '1'
                       : n2 == 64 ? best_reads < ell_reads
-                      : n2 == 32 ? false
+                      : n2 == 32 ? 10 * best_reads <= 7 * ell_reads  // (dense banks; the mel bank above: 46 against 60)
                                  : 5 * best_reads <= 4 * ell_reads || (slots >= 4 && best_reads < ell_reads);
     if (best_len && want) {
       const int len = best_len, nslots = best_rounds * 64, wstride = len + 4;

@@ -540,7 +540,8 @@ def test_segmented_and_ell_filter_walks_agree(bank, monkeypatch):
 
 
 @pytest.mark.parametrize("switch,value", [("PDS_STFT_FRONT", "mfma"), ("PDS_STFT_WALK", "ell"), ("PDS_STFT_WALK", "seg"),
-                                          ("PDS_STFT_WALK", "rseg"), ("PDS_STFT_WALK", "mseg")])
+                                          ("PDS_STFT_WALK", "rseg"), ("PDS_STFT_WALK", "mseg"),
+                                          ("PDS_N1024_GEOM", "32x32")])
 @pytest.mark.parametrize("name", ["c1_readme_fbank", "c2_tri_mel40", "c3_fbank80_energy", "c4_gabor64",
                                   "c5_gammatone64_48k"])
 def test_alternative_kernel_forms_match_the_oracle(switch, value, name, golden_meta, golden_tables, master_signal,
