@@ -72,6 +72,13 @@ WORKLOADS = {
          "frame_length_ms": 25, "frame_shift_ms": 10, "use_power": True},
         80000, 1024, None,
     ),
+    # 48 kHz audio, 20 ms / 10 ms framing with a mel bank: L = 960 -> N = 1024 (64 x 16, four frames per wave,
+    # row-segment walk; PDS_N1024_GEOM=32x32: two frames per wave)
+    "fbank80_48k_20_10_b256x10s": (
+        {"name": "stft", "bank": {"name": "fbank", "num_filts": 80, "sampling_rate": 48000},
+         "frame_length_ms": 20, "frame_shift_ms": 10, "use_power": True},
+        480000, 256, None,
+    ),
     # 48 kHz audio with the usual 25 ms / 10 ms framing: L = 1200 -> N = 2048 (64 x 32, two frames per wave)
     "fbank80_48k_25_10_b256x10s": (
         {"name": "stft", "bank": {"name": "fbank", "num_filts": 80, "sampling_rate": 48000},
