@@ -575,3 +575,30 @@ def test_alternative_kernel_forms_match_the_oracle(switch, value, name, golden_m
         y[1:] -= 0.97 * x[:-1].astype("f8")
         ok, msg = close(got[rows[b] : rows[b + 1]], orc.compute_full(y.astype("f4"), p), 2e-4, 2e-5, is_log=True)
         assert ok, (name, switch, value, b, msg)
+
+
+@pytest.mark.parametrize("name", ["c2_tri_mel40", "c4_gabor64", "c5_gammatone64_48k", "c3_fbank80_energy"])
+def test_ragged_scheduling_is_bit_identical(name, golden_meta, monkeypatch):
+    """pds_stft_batch_ragged_f32 (every wave one contiguous stretch of the chunks that exist) against the plain
+    launch (waves dealt (utterance, chunk) pairs, skipping those short utterances do not have): same rows, bit for
+    bit, on a batch with empty, one-frame and long utterances"""
+    import torch
+
+    import pydrobert_speech_amd as ps
+
+    comp = alias_factory_subclass_from_arg(FrameComputer, json.loads(json.dumps(golden_meta["configs"][name])))
+    rng = np.random.default_rng(5)
+    S = comp.frame_shift
+    lens = [0, 1, S, 7 * S + 3, 400 * S, 3 * S, 0, 55 * S, 2 * S, 900 * S + 11] + list(rng.integers(0, 60 * S, size=300))
+    x = torch.from_numpy((3000 * rng.standard_normal(int(np.sum(lens)))).astype("f4")).cuda()
+    offs = np.concatenate([[0], np.cumsum(lens)[:-1]])
+    layout = comp.prepare_layout(offs, lens, device=x.device)
+    assert layout.fill < 0.9
+    monkeypatch.setattr(ps.config, "RAGGED_SCHEDULING", True)
+    a = torch.full((layout.total_rows, comp.num_coeffs), float("nan"), device="cuda")
+    comp.launch(x, layout, out=a)
+    assert layout.d_work is not None  # (the ragged launch ran)
+    monkeypatch.setattr(ps.config, "RAGGED_SCHEDULING", False)
+    b = torch.full_like(a, float("nan"))
+    comp.launch(x, layout, out=b)
+    assert bool(torch.isfinite(a).all()) and torch.equal(a, b)
