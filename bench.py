@@ -168,7 +168,7 @@ def cpu_baseline(comp, n, budget_s=12.0):
     }
 
 
-def parity_spot_check(comp, signal, offsets, lengths, layout, out, picks=3, num_deltas=0):
+def parity_spot_check(comp, signal, offsets, lengths, layout, out, picks=3, num_deltas=0, preemph=0.0):
     """Rows of the buffer the timed region wrote, against the oracle on the same samples
 
     First, middle and last utterance of the batch: their signal slices go to the host, the oracle
@@ -192,6 +192,8 @@ def parity_spot_check(comp, signal, offsets, lengths, layout, out, picks=3, num_
     utts = sorted({0, B // 2, B - 1})[:picks]
     for b in utts:
         x = signal[int(offsets[b]) : int(offsets[b] + lengths[b])].cpu().numpy()
+        if preemph:
+            x = orc.preemphasize(x, preemph)
         want = orc.compute_full(x, p)
         r0 = int(layout.row_offsets[b])
         got = out[r0 : r0 + want.shape[0], :C].cpu().numpy().astype(np.float64)
@@ -270,6 +272,9 @@ def main():
                     help="deltas2 workloads: statics and deltas by one launch (the default where the plan has one)")
     ap.add_argument("--two-launch-deltas", action="store_true",
                     help="deltas2 workloads: the STFT launch followed by the deltas launch (A/B against the fused one)")
+    ap.add_argument("--preemph", type=float, default=0.0,
+                    help="pre-emphasis coefficient fused into the frame loads (reference pre.py:140-149 in front of "
+                         "compute_full); 0: none")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true")
     ap.add_argument("--generic", action="store_true",
@@ -365,18 +370,18 @@ def main():
 
     fused_deltas_used = bool(
         deltas is not None and not args.two_launch_deltas and not args.generic and args.dtype == "f32"
-        and not is_si and comp._native_plan(dev).has_fused_deltas)
+        and not args.preemph and not is_si and comp._native_plan(dev).has_fused_deltas)
 
     def step():
         nonlocal cmvn_out
         if is_si:
             comp.compute_packed(signal, offsets, lengths, out=out, direct=args.generic)
             return
-        if deltas is not None and not args.two_launch_deltas and not args.generic and args.dtype == "f32":
+        if deltas is not None and not args.two_launch_deltas and not args.generic and args.dtype == "f32" and not args.preemph:
             # statics and deltas by one launch where the plan has it (pds_stft_deltas_batch_f32), else the two
             comp.launch_with_deltas(signal, layout, deltas, out=out_wide if out_wide is not None else out, fused=True)
             return
-        comp.launch(signal, layout, out=out, generic=args.generic)
+        comp.launch(signal, layout, out=out, generic=args.generic, preemphasis=args.preemph)
         if deltas is not None:  # statics were written with row stride 3C; deltas go beside them
             deltas.apply_rows(out[:, :C], layout.row_offsets, out=out)
         if cmvn is not None:
@@ -456,7 +461,8 @@ def main():
         cpu = cpu_baseline(comp, n)
     spot = None
     if rank == 0 and not is_si:
-        spot = parity_spot_check(comp, signal, offsets, lengths, layout, out, num_deltas=2 if deltas is not None else 0)
+        spot = parity_spot_check(comp, signal, offsets, lengths, layout, out, num_deltas=2 if deltas is not None else 0,
+                                 preemph=args.preemph)
 
     def timed_gather():
         gathered = torch.empty((world * frames, out_cols), dtype=torch.float32, device=dev)
@@ -537,7 +543,8 @@ def main():
             "data": "synthetic",
             "config": {
                 "workload": args.workload + ("+ragged_1to15s" if args.ragged else "")
-                            + ("+float64_samples" if args.dtype == "f64in" else ""), "utterances_per_gpu": B,
+                            + ("+float64_samples" if args.dtype == "f64in" else "")
+                            + (f"+preemph{args.preemph:g}" if args.preemph else ""), "utterances_per_gpu": B,
                 "samples_per_utterance": int(lengths.mean()),
                 "frames_per_gpu_per_step": frames, "num_coeffs": comp.num_coeffs, "post": post,
                 "frame_length": comp.frame_length, "frame_shift": comp.frame_shift,

@@ -171,16 +171,24 @@ int32_t upload(T **dst, const T *src, size_t count) {
   return PDS_OK;
 }
 
-// x[i] - c x[i-1] in the signal's own precision, product rounded before the subtraction (the
-// multiply goes through asm so that -ffp-contract=fast cannot fuse it).  The reference's Preemphasize
-// (pre.py:140-149) and pre.hip's separate pass evaluate this in float64 and cast back, so for float64
-// signals the fused samples are bit-identical to theirs; for float32 signals the fused form uses
-// the float32 coefficient and float32 arithmetic and is within about one ulp per sample of them --
-// inside the feature tolerance (1e-4), not bit-identical.
+#ifndef PDS_PREEMPH_FMA
+#define PDS_PREEMPH_FMA 1
+#endif
+// x[i] - c x[i-1] in the signal's own precision.  The reference's Preemphasize (pre.py:140-149) and
+// pre.hip's separate pass evaluate this in float64 and cast back.  float64 signals: product rounded before
+// the subtraction (the multiply goes through asm so that -ffp-contract=fast cannot fuse it), so the fused
+// samples are bit-identical to theirs.  float32 signals: the float32 coefficient and ONE fused
+// multiply-add (one rounding; round 1 used a rounded product and a subtraction, 25 more instructions per
+// item): within about one ulp per sample of the reference's -- inside the feature tolerance (1e-4), not
+// bit-identical.
 __device__ __forceinline__ float preemph_sample(float cur, float prev, float c) {
+#if PDS_PREEMPH_FMA
+  return fmaf(-c, prev, cur);  // (one rounding: closer to the float64 value than the two of mul + sub; 25 instructions fewer per item)
+#else
   float t;
   asm("v_mul_f32 %0, %1, %2" : "=v"(t) : "v"(c), "v"(prev));
   return cur - t;
+#endif
 }
 __device__ __forceinline__ double preemph_sample(double cur, double prev, double c) {
   double t;
