@@ -56,8 +56,11 @@ namespace pds {
 // youngest first: +3 %).  One hex digit per phase in PDS_PRIO_PACK, from the lowest digit:
 // 0 record + sample loads, 1 LDS exchange, 2 power spectrum + P stores, 3 filter walk,
 // 4 window + in-lane real DFT, 5 N2-point FFT.  Negative: no hints (tools/build_variant.sh).
+// (Round 2, with the row-segment walk: record + sample loads at priority 2 instead of 0 -- a wave gets its 25
+// loads out at once and waits for them, instead of queueing for issue slots first -- headline +2.5 % on two
+// boxes, Gabor-64 +2.3 %, the other geometries +-0: 0x103212.)
 #ifndef PDS_PRIO_PACK
-#define PDS_PRIO_PACK 0x103210
+#define PDS_PRIO_PACK 0x103212
 #endif
 #if PDS_PRIO_PACK == 0xffffff  // (experiment: scheduling barriers at the phase boundaries, no priorities)
 #define PDS_PHASE(i) __builtin_amdgcn_sched_barrier(0)
