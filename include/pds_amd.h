@@ -135,7 +135,7 @@ int32_t pds_stft_batch_f64in(const pds_stft_plan *plan, const double *d_signal,
                              const int64_t *d_nframes, const int64_t *d_row_off, int32_t B,
                              int64_t max_frames, int32_t pad_left, double preemph, void *d_out,
                              int32_t out_is_f64, int64_t out_stride, void *stream);
-/* pds_stft_batch_f32 for RAGGED batches: the same kernels, but every wave walks one contiguous stretch of the
+/* pds_stft_batch_f32 (reference compute.py:574-607, compute_full per utterance) for RAGGED batches: the same kernels, but every wave walks one contiguous stretch of the
  * chunks that exist (the utterances' chunk counts are summed into `d_workspace`, B + 1 int64 on the device, by
  * a small kernel in front) instead of the waves being dealt (utterance, chunk < chunks of the longest) pairs of
  * which short utterances have none: lengths uniform in 1 ... 15 s run 9 % slower per frame than equal lengths
