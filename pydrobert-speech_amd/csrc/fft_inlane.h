@@ -190,6 +190,32 @@ PDS_HD void rdft_scaled(const float *a, float &even_sum, float &odd_sum, float *
   });
 }
 
+// The fifteen inter-stage twiddles W^k, k = 1..15, of one lane (W = e^{-2 pi i r / N}, a unit complex
+// number per lane) regenerated from three seeds w1 = W, w4 = W^4, w8 = W^8 instead of being held in
+// thirty registers: twelve complex products (48 instructions), none more than four products deep, so
+// a twiddle carries at most ~5 float32 roundings (tests/test_twiddle_chain.py replays this routine
+// against float64: max error 2e-7 over all lanes of the 32 x 16 geometry).  t[8] comes out DOUBLED:
+// the caller feeds rdft_scaled a window times 1/2, which makes that routine's outputs A[k] for
+// k != M/4 and A[M/4] / 2 (see rdft_scaled), so no twiddle needs a scale factor of its own.
+PDS_HD void cmul(float ar, float ai, float br, float bi, float &cr, float &ci) {
+  cr = fmaf(ar, br, -(ai * bi));
+  ci = fmaf(ar, bi, ai * br);
+}
+PDS_HD void twiddle_chain15(float w1r, float w1i, float w4r, float w4i, float w8r, float w8i, float *tr, float *ti) {
+  tr[1] = w1r, ti[1] = w1i;
+  tr[4] = w4r, ti[4] = w4i;
+  cmul(w1r, w1i, w1r, w1i, tr[2], ti[2]);
+  cmul(tr[2], ti[2], w1r, w1i, tr[3], ti[3]);
+  cmul(w1r, w1i, w4r, w4i, tr[5], ti[5]);
+  cmul(tr[2], ti[2], w4r, w4i, tr[6], ti[6]);
+  cmul(tr[3], ti[3], w4r, w4i, tr[7], ti[7]);
+  tr[8] = w8r + w8r, ti[8] = w8i + w8i;
+  static_for<1, 8>([&](auto kk) {
+    constexpr int k = decltype(kk)::value;
+    cmul(tr[k], ti[k], w8r, w8i, tr[8 + k], ti[8 + k]);
+  });
+}
+
 // cos / -sin of 2 pi K / M for the mixed-radix sizes (M divides 600)
 template <int M, int K>
 struct Tw600 {

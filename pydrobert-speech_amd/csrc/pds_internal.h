@@ -29,6 +29,8 @@ struct FastTables {
   float *d_window = nullptr;  // [n2][n1] window in lane order, zero padded
   float *d_twiddle = nullptr; // [n2][n1/2] (re, im) inter-stage twiddles in lane order
   float *d_tw_special = nullptr;  // [n2] (re, im) of e^{-2 pi i r / (2 n2)}
+  float *d_win_half = nullptr;    // prefetch instantiations (32 x 16): [n2][n1] window times 1/2
+  float *d_tw_seed = nullptr;     // ... and [n2][3] (re, im) twiddle seeds W_N^r, W_N^4r, W_N^8r
   float *d_ell_w = nullptr;       // ELL weight rows (see stft_fast.hip)
   int32_t *d_ell_meta = nullptr;  // [ell_slots][n2] first bin | (filter + 1) << 16
   int32_t *d_ell_len = nullptr;   // [ell_slots]

@@ -82,8 +82,11 @@ static unsigned long long *g_stamp_buf = nullptr;
 extern "C" __attribute__((visibility("default"))) void pds_debug_set_stamp_buffer(unsigned long long *d_buf) {
   g_stamp_buf = d_buf;
 }
+// (PDS_STAMPS=2: a wave's entry, loop start, loop end and item count only -- no stamps inside the loop, so the
+// build runs like the product; tools/wave_spread.py reads how evenly the waves finish)
 #define PDS_STAMP(i, drain)                                               \
   do {                                                                    \
+    if (PDS_STAMPS == 2) break;                                           \
     __builtin_amdgcn_sched_barrier(0);                                    \
     if (drain) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           \
     const unsigned long long now_ = __builtin_readcyclecounter();         \
@@ -133,6 +136,36 @@ extern "C" __attribute__((visibility("default"))) void pds_debug_set_stamp_buffe
 #ifndef PDS_FILTER_UNROLL
 #define PDS_FILTER_UNROLL 2
 #endif
+// PF instantiations (the next item's samples prefetched into registers, see the kernel):
+// PDS_PF_TW   inter-stage twiddles: 0 thirty registers (as without PF), 1 regenerated per item from three seeds
+// PDS_PF_WIN  window slice: 0 registers, 1 re-read from an LDS table per item (16-byte reads)
+// PDS_PF_PLACE where the prefetch loads are issued: 0 behind the exchange (in front of the column transforms),
+//             1 in front of the filter walk
+// PDS_PF_ILV  vector instructions the scheduler is asked to put between two prefetch loads (0: its own choice)
+// Round-3 experiments, measured and NOT in the product build (profiles/r3a_*.txt):
+// -DPDS_EXPERIMENTS=1 builds the prefetch instantiation (PF) and its tables, -DPDS_DYN=1 the dynamic item
+// distribution inside a workgroup (DYN); tools/ab_pf.sh and tools/ab_dyn.sh run the comparisons.
+#ifndef PDS_EXPERIMENTS
+#define PDS_EXPERIMENTS 0
+#endif
+#ifndef PDS_DYN
+#define PDS_DYN 0
+#endif
+#ifndef PDS_PF_TW
+#define PDS_PF_TW 1
+#endif
+#ifndef PDS_PF_WIN
+#define PDS_PF_WIN 0
+#endif
+#ifndef PDS_PF_PLACE
+#define PDS_PF_PLACE 0
+#endif
+#ifndef PDS_PF_WINAT  // (WINLDS: the window slice is re-read 0 inside a walk round, behind its reads, 1 behind the rounds)
+#define PDS_PF_WINAT 1
+#endif
+#ifndef PDS_PF_ILV
+#define PDS_PF_ILV 0
+#endif
 __device__ __forceinline__ void keep_alive(float v) { asm volatile("" ::"v"(v)); }
 
 struct FastParams {
@@ -143,6 +176,8 @@ struct FastParams {
   const float *win_lane;    // [N2][N1]   window[N2*n1 + n2], zero beyond L
   const float2 *tw_lane;    // [N2][N1/2] W_N^(n2*k1), pre-scaled (see rdft_scaled)
   const float2 *tw_special; // [N2] e^{-2 pi i r / (2 N2)}
+  const float *win_half;    // PF: [N2][N1] the window times 1/2 (see twiddle_seeds)
+  const float2 *tw_seed;    // PF: [N2][3] W_N^(n2), W_N^(4 n2), W_N^(8 n2), unscaled
   const float *ell_w;       // per slot: [N2][len + 4] dense weight rows (row j = lane j's filter)
   const int32_t *ell_meta;  // [slots][N2] first bin of the row | (filter + 1) << 16
   const int32_t *ell_len;   // [slots] row length in bins (multiple of 8)
@@ -157,6 +192,9 @@ struct FastParams {
   double preemph_d;  // the coefficient at full precision (float64 samples)
   int chunks_per_utt, num_utts;
   int waves;  // wavefronts per workgroup of this launch (<= MAXWAVES)
+  unsigned waves_rcp;  // ceil(2^32 / waves): ticket / waves as a multiply-high (tickets < 2^28)
+  int lds_ticket_off;  // floats from the start of the workgroup's LDS to its ticket counter
+  int dyn;             // items handed out by the workgroup's ticket counter (0: static round-robin)
   const float *mf_tab;  // matrix-pipe front end (MF instantiations): image of MfmaFrontTables
   unsigned long long *stamps;  // diagnostic builds (PDS_STAMPS): [grid waves][12] phase times and absolute times, else null
   // fused statics + deltas launches (DLT instantiations): every wave walks ONE contiguous stretch of the
@@ -275,8 +313,16 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // of the reference's drivers (float64 audio in, compute.py:601 output dtype = input dtype) without
 // separate conversion passes over the signal and the features.
 template <int N1, int N2, int NROWS, int MAXWAVES, int MINW, bool ELL_LDS, bool PRE, int SEG = 0, int MF = 0,
-          bool RSG = false, typename TIN = float, typename TOUT = float, int DLT = 0, bool STR = false>
+          bool RSG = false, typename TIN = float, typename TOUT = float, int DLT = 0, bool STR = false, bool PF = false>
 __global__ __launch_bounds__(MAXWAVES * 64, MINW) void stft_wave_kernel(const FastParams p) {
+  // PF: the NEXT item's samples are loaded into registers while this item's column transforms and filter
+  // walk run (a wave's own frame loads -- issue and wait -- were 27 % of its item, profiles/r2b_phase_stamps.txt).
+  // The registers come from the inter-stage twiddles: instead of thirty loop-invariant registers the lane keeps
+  // three seeds W^r, W^4r, W^8r and regenerates W^(r k1), k1 = 1..15, per item by twelve complex products at
+  // most four deep (twiddle_chain; tests/test_twiddle_chain.py replays it against float64).  The next item's
+  // utterance record is fetched at the top of the item for that.
+  static_assert(!PF || (DLT == 0 && !STR && MF == 0 && !PRE && std::is_same<TIN, float>::value && N1 == 32 && N2 == 16),
+                "prefetch: 32 x 16 geometry, float32 samples, round-robin scheduling");
   // STR: the stretch scheduling of the DLT launches without their deltas -- every wave walks one contiguous
   // stretch of the batch's EXISTING chunks (chunk_prefix) -- for ragged batches: dealt round-robin over
   // (utterance, chunk < chunks of the longest) the waves skip the chunks short utterances do not have and end
@@ -333,7 +379,31 @@ __global__ __launch_bounds__(MAXWAVES * 64, MINW) void stft_wave_kernel(const Fa
   float2 *sw_lds = reinterpret_cast<float2 *>(smem + p.waves * (G::EXCH_F2 * 2));  // [N2]
   int *meta_lds = reinterpret_cast<int *>(sw_lds + N2);
   float *ellw_lds = reinterpret_cast<float *>(meta_lds + p.ell_meta_pad);
+  constexpr bool TWCHAIN = PF && PDS_PF_TW == 1;  // twiddles regenerated per item; window times 1/2
+  constexpr bool WINLDS = PF && PDS_PF_WIN == 1;  // window slice re-read from LDS per item
+  constexpr int WSTR = ((NROWS + 3) & ~3) % 8 == 4 ? ((NROWS + 3) & ~3) : ((NROWS + 3) & ~3) + 4;  // row stride = 4 (mod 8) floats: conflict-free 16-byte reads
+  [[maybe_unused]] float *win_lds = ellw_lds + (ELL_LDS ? p.ell_wfloats : 0);  // [N2][WSTR]
+  if constexpr (WINLDS) {
+    const float *wsrc = TWCHAIN ? p.win_half : p.win_lane;
+    for (int i = threadIdx.x; i < N2 * WSTR; i += p.waves * 64) {
+      const int rr = i / WSTR, k = i - rr * WSTR;
+      win_lds[i] = k < NROWS ? wsrc[rr * N1 + k] : 0.0f;
+    }
+  }
   if (threadIdx.x < N2) sw_lds[threadIdx.x] = p.tw_special[threadIdx.x];
+  // DYN: the workgroup's waves draw their items from one ticket counter in LDS instead of taking every
+  // (grid waves)-th item each.  The four waves of a SIMD do not run at the same pace (the issue arbiter
+  // prefers the older wave, and the priorities that keep them staggered add to it): with equal shares
+  // the waves of one CU finished between 430 000 and 500 000 cycles of a launch (tools/wave_spread.py),
+  // i.e. the last tenth of a launch ran on a draining CU.  Ticket t of workgroup w is item
+  // (t / waves) * (grid waves) + w * waves + t % waves -- the same items as before, so neighbouring
+  // waves still work on neighbouring chunks at about the same time -- and a wave fetches its next
+  // ticket (one ds_add_rtn) at the top of an item, a filter walk ahead of needing it.
+  constexpr bool DYN = PDS_DYN && !STRETCH && !PF;
+  [[maybe_unused]] int *ticket_lds = reinterpret_cast<int *>(smem + p.lds_ticket_off);
+  if constexpr (DYN) {
+    if (threadIdx.x == 0) *ticket_lds = p.waves;  // (tickets 0 .. waves - 1 are the waves' first items)
+  }
   // (slots beyond the table read as "no filter": the unrolled slot loop fetches USLOTS entries)
   for (int i = threadIdx.x; i < p.ell_meta_pad; i += nthreads)
     meta_lds[i] = i < p.ell_meta_ints ? p.ell_meta[i] : 0;
@@ -361,8 +431,9 @@ __global__ __launch_bounds__(MAXWAVES * 64, MINW) void stft_wave_kernel(const Fa
 
   // per-lane constants, loop invariant: window slice and inter-stage twiddles (issued in front of the LDS
   // set-up instead: measured slower, 0.0328 against 0.0308 ms at 64 utterances)
-  [[maybe_unused]] float win[MF ? 1 : NROWS];
-  [[maybe_unused]] float twr[MF ? 1 : COLS], twi[MF ? 1 : COLS];
+  [[maybe_unused]] float win[(MF || WINLDS) ? 1 : NROWS];
+  [[maybe_unused]] float twr[(MF || TWCHAIN) ? 1 : COLS], twi[(MF || TWCHAIN) ? 1 : COLS];
+  [[maybe_unused]] float sd[6] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};  // TWCHAIN: the seeds W^r, W^4r, W^8r
   // MF: window and byte offset of the lane's sample slots, A operands of the two chains, twiddles of
   // the lane's four output rows
   [[maybe_unused]] float mwin[MSLOTS], mare[MF + 1], maim[MF + 1], mtwr[4], mtwi[4];
@@ -386,15 +457,50 @@ __global__ __launch_bounds__(MAXWAVES * 64, MINW) void stft_wave_kernel(const Fa
       mtwi[v] = t.y;
     }
   } else {
+    if constexpr (!WINLDS) {
+      const float *wsrc = TWCHAIN ? p.win_half : p.win_lane;
 #pragma unroll
-    for (int n1 = 0; n1 < NROWS; ++n1) win[n1] = p.win_lane[rho * N1 + n1];
+      for (int n1 = 0; n1 < NROWS; ++n1) win[n1] = wsrc[rho * N1 + n1];
+    }
+    if constexpr (TWCHAIN) {
 #pragma unroll
-    for (int k1 = 1; k1 <= NREG; ++k1) {
-      const float2 t = p.tw_lane[rho * COLS + k1];
-      twr[k1] = t.x;
-      twi[k1] = t.y;
+      for (int j = 0; j < 3; ++j) {
+        const float2 t = p.tw_seed[rho * 3 + j];
+        sd[2 * j] = t.x;
+        sd[2 * j + 1] = t.y;
+      }
+    } else {
+#pragma unroll
+      for (int k1 = 1; k1 <= NREG; ++k1) {
+        const float2 t = p.tw_lane[rho * COLS + k1];
+        twr[k1] = t.x;
+        twi[k1] = t.y;
+      }
     }
   }
+  // PF: the next item's samples (in flight from the middle of an item to the top of the next) and whether
+  // they are the next item's at all (a regular item: all frames exist, every row inside the signal)
+  [[maybe_unused]] float pfv[PF ? NROWS : 1];
+  // WINLDS: the window slice lives in registers from the end of an item's filter walk to the top of the next item
+  // only (read from the LDS table behind the walk's own reads, so that the round trip is not the first thing an
+  // item waits for); the column transforms, where the registers are scarce, run without it
+  [[maybe_unused]] float wl[WINLDS ? NROWS : 1];
+  [[maybe_unused]] auto read_window = [&]() {
+    if constexpr (WINLDS) {
+      const float4 *w4 = reinterpret_cast<const float4 *>(win_lds + rho * WSTR);
+#pragma unroll
+      for (int j = 0; j < (NROWS + 3) / 4; ++j) {
+        const float4 w = w4[j];
+        const float wv[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          if (4 * j + u < NROWS) wl[4 * j + u] = wv[u];
+      }
+    }
+  };
+  read_window();
+  [[maybe_unused]] bool pf_ready = false;
+  [[maybe_unused]] const int pf_lane = __mul24(g, p.S) + r;  // the lane's first sample inside an item's stretch
   const int L = p.L, S = p.S;
   const bool use_power = p.use_power != 0;
   const int col0 = p.include_energy ? 1 : 0;
@@ -419,6 +525,48 @@ __global__ __launch_bounds__(MAXWAVES * 64, MINW) void stft_wave_kernel(const Fa
       ++b;
     }
   }
+  // DYN: (rb, rc) = utterance and chunk of the workgroup's first item of round `rnd` (items
+  // rnd * (grid waves) + wg * waves + 0 .. waves - 1); a wave moves it forward to its ticket's round
+  [[maybe_unused]] int rnd = 0, rb = 0, rc = wg * p.waves;
+  if constexpr (DYN) {
+    while (rc >= p.chunks_per_utt && rb < p.num_utts) {
+      rc -= p.chunks_per_utt;
+      ++rb;
+    }
+  }
+  // sets (b, chunk) to ticket t's item; b >= num_utts: no such item (and none for any later ticket)
+  [[maybe_unused]] auto take_ticket = [&](const int t) {
+    const int jn = (int)__umulhi((unsigned)t, p.waves_rcp), o = t - jn * p.waves;
+    while (rnd < jn && rb < p.num_utts) {  // (one step per item taken in the steady state)
+      rc += p.step_chunks;
+      rb += p.step_utts;
+      if (rc >= p.chunks_per_utt) {
+        rc -= p.chunks_per_utt;
+        ++rb;
+      }
+      ++rnd;
+    }
+    b = rb;
+    chunk = rc + o;
+    while (chunk >= p.chunks_per_utt && b < p.num_utts) {
+      chunk -= p.chunks_per_utt;
+      ++b;
+    }
+  };
+  [[maybe_unused]] int ticket_v = 0;  // lane 0: the wave's next ticket, in flight from the top of an item
+  [[maybe_unused]] auto fetch_ticket = [&]() {
+    if (lane == 0) ticket_v = __hip_atomic_fetch_add(ticket_lds, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  };
+  // the next item's (b, chunk) and its utterance record
+  [[maybe_unused]] auto next_item_dyn = [&](int &nfr_, int &n_, int64_t &sig_off_, int64_t &out_row_) {
+    const int last_b = b;
+    take_ticket(__builtin_amdgcn_readfirstlane(ticket_v));
+    const int pb_ = b < p.num_utts ? b : last_b;  // (any valid record past the end)
+    nfr_ = (int)load_const(p.nframes + pb_);
+    n_ = (int)load_const(p.lengths + pb_);
+    sig_off_ = load_const(p.offsets + pb_);
+    out_row_ = load_const(p.row_off + pb_);
+  };
   // The utterance record of an item (frame count, length, signal offset, output row) is fetched
   // during the filter phase of the item before: four dependent scalar-load round trips at the
   // top of every item otherwise.
@@ -601,7 +749,14 @@ __global__ __launch_bounds__(MAXWAVES * 64, MINW) void stft_wave_kernel(const Fa
     }
     const int pb = nb < p.num_utts ? nb : b;  // record to fetch (any valid one past the end)
     const int tb = chunk * G::GROUPS;  // first frame of the chunk (frames * S fits an int)
+    if constexpr (DYN) {
+      if (p.dyn) fetch_ticket();
+    }
     if (!STRETCH && tb >= nfr) {  // uniform: utterance shorter than the longest
+      if (DYN && p.dyn) {
+        next_item_dyn(nfr, n, sig_off, out_row);
+        continue;
+      }
       b = nb;
       chunk = nchunk;
       nfr = (int)load_const(p.nframes + pb);
@@ -611,8 +766,37 @@ __global__ __launch_bounds__(MAXWAVES * 64, MINW) void stft_wave_kernel(const Fa
       continue;
     }
     PDS_STAMP(7, 0);  // item bookkeeping (and whatever the previous item left undrained)
-    if constexpr (PDS_STAMPS) ++st_acc[6];
+    if constexpr (PDS_STAMPS != 0) ++st_acc[6];
     PDS_PHASE(0);
+    // PF: the next item's record now (it is needed in the middle of this item, for the prefetch)
+    [[maybe_unused]] int nfr_nx = 0, n_nx = 0;
+    [[maybe_unused]] int64_t sig_off_nx = 0, out_row_nx = 0;
+    // (issued behind the window multiplies: scalar loads return out of order, so the next wait for an LDS read
+    // is a wait for them too -- from there the in-lane transform covers them)
+    [[maybe_unused]] auto fetch_next_record = [&]() {
+      __builtin_amdgcn_sched_barrier(0);
+      nfr_nx = (int)load_const(p.nframes + pb);
+      n_nx = (int)load_const(p.lengths + pb);
+      sig_off_nx = load_const(p.offsets + pb);
+      out_row_nx = load_const(p.row_off + pb);
+    };
+    // the prefetch: 25 loads whatever the next item is -- an item that is not regular (or none) re-reads the
+    // lane's window slice instead, so that the loads sit in straight-line code the scheduler may spread over
+    // the arithmetic that follows (a branch around them would pin them in a block of their own)
+    [[maybe_unused]] auto issue_prefetch = [&]() {
+      const int tb2 = nchunk * G::GROUPS, s02 = tb2 * S - p.pad_left;
+      pf_ready = nb < p.num_utts && tb2 + G::GROUPS <= nfr_nx && s02 >= 0 && s02 + (G::GROUPS - 1) * S + LOADSPAN <= n_nx;
+      const float *base = pf_ready ? static_cast<const float *>(p.sig) + (sig_off_nx + s02) : p.win_lane;
+      const float *xp2 = base + (pf_ready ? pf_lane : r);
+#pragma unroll
+      for (int n1 = 0; n1 < NROWS; ++n1) {
+        pfv[n1] = xp2[n1 * N2];
+#if PDS_PF_ILV > 0
+        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);          // one load
+        __builtin_amdgcn_sched_group_barrier(0x002, PDS_PF_ILV, 0);  // then vector instructions of what follows
+#endif
+      }
+    };
     const TIN *x = static_cast<const TIN *>(p.sig) + sig_off;
     const int start0 = tb * S - p.pad_left;
     bool valid = true;
@@ -782,7 +966,7 @@ __global__ __launch_bounds__(MAXWAVES * 64, MINW) void stft_wave_kernel(const Fa
       // gathered with reflected indices (1: one bounce suffices, 2: general reflection).
       int start = start0 + __mul24(g, S);  // (24-bit multiplies issue at full rate, 32-bit ones at a quarter)
       int wmode = 0;
-      if (!(tb + G::GROUPS <= nfr && start0 >= (PRE ? 1 : 0) &&
+      if (!(PF && pf_ready) && !(tb + G::GROUPS <= nfr && start0 >= (PRE ? 1 : 0) &&
             start0 + (G::GROUPS - 1) * S + LOADSPAN <= n)) {
         valid = tb + g < nfr;
         start = (valid ? tb + g : nfr - 1) * S - p.pad_left;
@@ -794,7 +978,11 @@ __global__ __launch_bounds__(MAXWAVES * 64, MINW) void stft_wave_kernel(const Fa
       }
 
       float a[N1];
-      if (wmode == 0) {
+      if (PF && pf_ready) {
+        // (a regular item by construction: wmode = 0, valid)
+#pragma unroll
+        for (int n1 = 0; n1 < NROWS; ++n1) a[n1] = pfv[n1];
+      } else if (wmode == 0) {
         // Lanes past the frame's end in the last row read samples of the next frame; the
         // window (exactly 0 there, applied with the 0 * x = 0 multiply) removes them.
         const TIN *xp = x + (start + r);
@@ -905,8 +1093,14 @@ __global__ __launch_bounds__(MAXWAVES * 64, MINW) void stft_wave_kernel(const Fa
       PDS_STAMP(0, 0);  // frame loads issued
       PDS_STAMP(1, 1);  // ... and arrived
       PDS_PHASE(4);
+      if constexpr (WINLDS) {
 #pragma unroll
-      for (int n1 = 0; n1 < NROWS; ++n1) a[n1] = mul_legacy(a[n1], win[n1]);
+        for (int n1 = 0; n1 < NROWS; ++n1) a[n1] = mul_legacy(a[n1], wl[n1]);
+      } else {
+#pragma unroll
+        for (int n1 = 0; n1 < NROWS; ++n1) a[n1] = mul_legacy(a[n1], win[n1]);
+      }
+      if constexpr (PF) fetch_next_record();
 #pragma unroll
       for (int n1 = NROWS; n1 < N1; ++n1) a[n1] = 0.0f;
 
@@ -934,11 +1128,15 @@ __global__ __launch_bounds__(MAXWAVES * 64, MINW) void stft_wave_kernel(const Fa
         row0[rho] = even_sum;
         row0[N2 + rho] = odd_sum;
       }
+      [[maybe_unused]] float ctr[TWCHAIN ? COLS : 1], cti[TWCHAIN ? COLS : 1];
+      if constexpr (TWCHAIN) inl::twiddle_chain15(sd[0], sd[1], sd[2], sd[3], sd[4], sd[5], ctr, cti);
 #pragma unroll
       for (int k1 = 1; k1 <= NREG; ++k1) {
+        const float wr_ = TWCHAIN ? ctr[TWCHAIN ? k1 : 0] : twr[TWCHAIN ? 0 : k1];
+        const float wi_ = TWCHAIN ? cti[TWCHAIN ? k1 : 0] : twi[TWCHAIN ? 0 : k1];
         float2 v;
-        v.x = Ar[k1] * twr[k1] - Ai[k1] * twi[k1];
-        v.y = Ar[k1] * twi[k1] + Ai[k1] * twr[k1];
+        v.x = Ar[k1] * wr_ - Ai[k1] * wi_;
+        v.y = Ar[k1] * wi_ + Ai[k1] * wr_;
         if constexpr (PDS_ABLATE & 4) {
           Ar[k1] = v.x;
           Ai[k1] = v.y;
@@ -1042,6 +1240,16 @@ __global__ __launch_bounds__(MAXWAVES * 64, MINW) void stft_wave_kernel(const Fa
         zr[2 * j + 1] = v.z;
         zi[2 * j + 1] = v.w;
       }
+      // PF: the next item's loads behind this item's column reads (which the transform waits for), spread over
+      // the transform's arithmetic
+      // (the transform's priority is set in front of them: s_setprio is a scheduling boundary)
+      if constexpr (PF && PDS_PF_PLACE == 0) {
+        PDS_PHASE(5);
+#if PDS_PF_ILV > 0
+        __builtin_amdgcn_sched_group_barrier(0x100, N2 / 2, 0);  // the column reads first
+#endif
+        if (q == 0) issue_prefetch();
+      }
       if constexpr (PDS_ABLATE & 8) {
 #pragma unroll
         for (int k2 = 0; k2 < N2; ++k2) {
@@ -1049,7 +1257,7 @@ __global__ __launch_bounds__(MAXWAVES * 64, MINW) void stft_wave_kernel(const Fa
           Yi[k2] = zi[k2];
         }
       } else {
-        PDS_PHASE(5);
+        if constexpr (!(PF && PDS_PF_PLACE == 0)) PDS_PHASE(5);
         inl::CFFT<N2, 1>::run(zr, zi, Yr, Yi);
         if (q + 1 < G::CPL) {
           PDS_PHASE(1);
@@ -1101,8 +1309,9 @@ __global__ __launch_bounds__(MAXWAVES * 64, MINW) void stft_wave_kernel(const Fa
         const float ti = sw.y * di - sw.x * dr;
         const float xr = sr + tr, xi = si + ti;  // 2 X[m]
         const float yr = sr - tr, yi = ti - si;  // 2 X[N2 - m]
-        sp0 = 0.25f * (xr * xr + xi * xi);
-        sp1 = 0.25f * (yr * yr + yi * yi);
+        // (TWCHAIN: the window carries the factor 1/2 already)
+        sp0 = (TWCHAIN ? 1.0f : 0.25f) * (xr * xr + xi * xi);
+        sp1 = (TWCHAIN ? 1.0f : 0.25f) * (yr * yr + yi * yi);
       }
     }
     if (!use_power) {
@@ -1214,6 +1423,16 @@ __global__ __launch_bounds__(MAXWAVES * 64, MINW) void stft_wave_kernel(const Fa
     // this item's record is dead from here on: fetch the next one under the filter phase
     if constexpr (STRETCH) {
       // (the piece's record stays)
+    } else if constexpr (PF) {
+      b = nb;
+      chunk = nchunk;
+      nfr = nfr_nx;
+      n = n_nx;
+      sig_off = sig_off_nx;
+      out_row = out_row_nx;
+      if constexpr (PDS_PF_PLACE == 1) issue_prefetch();
+    } else if (DYN && p.dyn) {
+      next_item_dyn(nfr, n, sig_off, out_row);
     } else {
       b = nb;
       chunk = nchunk;
@@ -1328,6 +1547,9 @@ __global__ __launch_bounds__(MAXWAVES * 64, MINW) void stft_wave_kernel(const Fa
 #pragma unroll 2
           for (int t4 = 0; t4 < t4n; ++t4) quad(t4);
         }
+#if PDS_PF_WINAT == 0
+        read_window();  // (WINLDS: the next item's window slice, behind this round's reads)
+#endif
         // add up a filter's segments (at most four, on consecutive lanes of one DPP row): lane i takes
         // lane i + 1's sums where the table says the run continues, then lane i + 2's
         const float m1 = (meta & (1 << 14)) ? 1.0f : 0.0f, m2 = (meta & (1 << 15)) ? 1.0f : 0.0f;
@@ -1361,6 +1583,9 @@ __global__ __launch_bounds__(MAXWAVES * 64, MINW) void stft_wave_kernel(const Fa
       if constexpr (DLT == 0) {
         float unused[4];
         for (int rd = 0; rd < p.seg_rounds; ++rd) round_body(rd, unused);
+#if PDS_PF_WINAT == 1
+        read_window();  // (WINLDS: the next item's window slice)
+#endif
       } else {
         // the chunk's logged coefficients: the lane's filter of every round, the energies on their lane
         float cur[DR][4];
@@ -1524,7 +1749,7 @@ __global__ __launch_bounds__(MAXWAVES * 64, MINW) void stft_wave_kernel(const Fa
 #pragma unroll
           for (int gg = 0; gg < G::GROUPS; ++gg) dst[gg] = acc[gg];
         }
-        if constexpr (PDS_STAMPS > 1) PDS_STAMP(4, 0);  // (diagnostic: the rounds go to slot 4, the sums and stores stay in 5)
+        if constexpr (PDS_STAMPS > 2) PDS_STAMP(4, 0);  // (diagnostic: the rounds go to slot 4, the sums and stores stay in 5)
         wave_sync();
         const int *fmeta = meta_lds + p.seg_rounds * (SEG == 2 ? 16 : 64);
         constexpr int PSTEP = SEG == 2 ? 4 : 1;  // a filter's partial sums: consecutive slots, or a quad apart
@@ -1662,6 +1887,8 @@ static int32_t launch_wave(const pds_stft_plan *plan, const BatchArgs &a) {
   p.win_lane = ft.d_window;
   p.tw_lane = (const float2 *)ft.d_twiddle;
   p.tw_special = (const float2 *)ft.d_tw_special;
+  p.win_half = nullptr;
+  p.tw_seed = nullptr;
   p.ell_w = ft.d_ell_w;
   p.ell_meta = ft.d_ell_meta;
   p.ell_len = ft.d_ell_len;
@@ -1693,6 +1920,9 @@ static int32_t launch_wave(const pds_stft_plan *plan, const BatchArgs &a) {
   const size_t lds_cu = 160 * 1024;
   const size_t per_wave = (size_t)G::EXCH_F2 * 8;
   int shapes[4][2] = {{CU_WAVES / 2, 2}, {CU_WAVES, 1}, {CU_WAVES * 3 / 4, 1}, {CU_WAVES * 5 / 8, 1}};
+#ifdef PDS_ONE_WG  // (experiment: one workgroup per CU whatever fits)
+  shapes[0][0] = CU_WAVES, shapes[0][1] = 1;
+#endif
   if (CU_WAVES % 8 != 0) {
     // (three waves per SIMD: two workgroups of six waves do not tile the four SIMDs -- the second one of a
     // CU waited for the first to finish, measured as a launch twice as long -- one of twelve does)
@@ -1714,6 +1944,14 @@ static int32_t launch_wave(const pds_stft_plan *plan, const BatchArgs &a) {
   int walk = 0;
   // (fused deltas exist for the row-segment walk only: take it whatever the plan prefers)
   const bool dl = a.dl_K > 0 && ft.rsn_rounds > 0;  // (its own table: numbered order)
+  // prefetch instantiation (PF): 32 x 16 geometry with the row-segment walk, float32 samples, round-robin
+  // scheduling (PDS_STFT_PF=0 keeps the kernel without it)
+  constexpr bool PFG = N1 == 32 && N2 == 16;
+  const char *pf_env = std::getenv("PDS_STFT_PF");
+  const bool pf_ok = PDS_EXPERIMENTS && PFG && !pre && !a.in_f64 && !a.stretch && a.dl_K == 0 && ft.d_win_half &&
+                     ft.d_tw_seed && !(pf_env && pf_env[0] == '0');
+  constexpr int PF_WSTR = ((NROWS + 3) & ~3) % 8 == 4 ? ((NROWS + 3) & ~3) : ((NROWS + 3) & ~3) + 4;
+  const size_t pf_extra = (PDS_PF_WIN == 1) ? (size_t)N2 * PF_WSTR * 4 : 0;  // window table in LDS
   constexpr bool MSG = G::GROUPS == 4 && inl::is_pow2(N1);  // matrix-pipe segment walk instantiated
   constexpr bool SEGOK = G::GROUPS == 4 || (inl::is_pow2(N1) && N2 >= 32);  // segmented walk instantiated
   for (int cand = (G::GROUPS == 4) ? (dl ? 2 : ft.walk) : (SEGOK && ft.walk == 1 ? 1 : 0); cand >= 0 && !in_lds; --cand) {
@@ -1722,13 +1960,13 @@ static int32_t launch_wave(const pds_stft_plan *plan, const BatchArgs &a) {
     if ((cand == 2 && !dl && ft.rs_rounds == 0) || (cand == 1 && (ft.seg_rounds == 0 || pre || a.in_f64))) continue;
     const int meta_ints = cand == 3 ? ft.ms_meta_ints : cand == 2 ? (dl ? ft.rsn_rounds : ft.rs_rounds) * 64 : cand == 1 ? ft.seg_meta_ints : ft.ell_slots * N2;
     const int meta_pad = (std::max(meta_ints, USLOTS * N2) + 3) / 4 * 4;
-    const size_t fixed = (size_t)N2 * 8 + (size_t)meta_pad * 4;
+    const size_t fixed = (size_t)N2 * 8 + (size_t)meta_pad * 4 + (cand == 2 && pf_ok ? pf_extra : 0);
     const size_t table_bytes = (size_t)(cand == 3 ? ft.ms_wfloats : cand == 2 ? (dl ? ft.rsn_wfloats : ft.rs_wfloats) : cand == 1 ? ft.seg_wfloats : ft.ell_wfloats) * 4;
     // (segment sums live behind P in the wave's area)
     if (cand == 1 && (size_t)G::GROUPS * G::PSTR * 4 + (size_t)ft.seg_rounds * 64 * 4 * G::GROUPS > per_wave) continue;
     if (cand == 3 && (size_t)G::GROUPS * G::PSTR * 4 + (size_t)ft.ms_rounds * 64 * 16 > per_wave) continue;
     for (const auto &shape : shapes)
-      if (shape[0] * per_wave + fixed + table_bytes <= lds_cu / shape[1]) {
+      if (shape[0] * per_wave + fixed + table_bytes + 32 <= lds_cu / shape[1]) {  // (+ the ticket counter)
         waves = shape[0];
         wgs_per_cu = shape[1];
         in_lds = true;
@@ -1760,7 +1998,7 @@ static int32_t launch_wave(const pds_stft_plan *plan, const BatchArgs &a) {
 #ifdef PDS_FORCE_WAVES  // (experiment: throughput against resident waves per CU, two workgroups per CU)
   if (in_lds && PDS_FORCE_WAVES <= CU_WAVES / 2) waves = PDS_FORCE_WAVES, wgs_per_cu = 2;
 #endif
-  const size_t fixed = (size_t)N2 * 8 + (size_t)p.ell_meta_pad * 4;
+  const size_t fixed = (size_t)N2 * 8 + (size_t)p.ell_meta_pad * 4 + (walk == 2 && in_lds && pf_ok ? pf_extra : 0);
   const size_t table_bytes = (size_t)p.ell_wfloats * 4;
   // the fused pre-emphasis variant exists for LDS-resident tables only; the rare other case
   // (dense complex bank at N >= 1024 plus pre-emphasis) takes the direct-DFT kernel
@@ -1774,7 +2012,15 @@ static int32_t launch_wave(const pds_stft_plan *plan, const BatchArgs &a) {
 #else
   p.stamps = nullptr;
 #endif
-  const size_t smem = waves * per_wave + fixed + (in_lds ? table_bytes : 0);
+  size_t smem = waves * per_wave + fixed + (in_lds ? table_bytes : 0);
+  smem = (smem + 15) & ~(size_t)15;
+  p.lds_ticket_off = (int)(smem / 4);  // the workgroup's ticket counter
+  smem += 16;
+  p.waves_rcp = (unsigned)((0x100000000ull + (unsigned)waves - 1) / (unsigned)waves);
+  {
+    const char *dyn_env = std::getenv("PDS_STFT_DYN");
+    p.dyn = (dyn_env && dyn_env[0] == '0') ? 0 : 1;
+  }
   constexpr bool W4 = G::GROUPS == 4;  // the walks over four frames exist for the 16-lane geometries
   const bool seg = SEGOK && (walk == 1 || walk == 3), rsg = W4 && walk == 2, mseg = MSG && walk == 3;
   auto kern = pre      ? (rsg ? stft_wave_kernel<N1, N2, NROWS, CU_WAVES_K, MINW, true, true, false, 0, W4>
@@ -1798,6 +2044,17 @@ static int32_t launch_wave(const pds_stft_plan *plan, const BatchArgs &a) {
                    : stft_wave_kernel<N1, N2, NROWS, CU_WAVES_K, MINW, true, false, false, MFS>;
     }
   }
+  bool pf_used = false;
+#if PDS_EXPERIMENTS
+  if constexpr (PFG) {
+    if (pf_ok && rsg && in_lds && !mf) {
+      pf_used = true;
+      kern = stft_wave_kernel<N1, N2, NROWS, CU_WAVES_K, MINW, true, false, 0, 0, W4, float, float, 0, false, PFG>;
+      p.win_half = ft.d_win_half;
+      p.tw_seed = (const float2 *)ft.d_tw_seed;
+    }
+  }
+#endif
   // ragged batches (pds_stft_batch_ragged_f32): the same kernels with stretch scheduling (STR); float32 samples
   // without fused pre-emphasis, in-lane front end
   bool str_used = false;
@@ -1870,6 +2127,7 @@ static int32_t launch_wave(const pds_stft_plan *plan, const BatchArgs &a) {
   static std::atomic<size_t> attr_smem[kDevices][32];
   const int which = dl_which >= 0    ? dl_which
                     : f64_which >= 0 ? f64_which
+                    : pf_used        ? 27
                     : str_used       ? 22 + (rsg ? 0 : mseg ? 1 : seg ? 2 : in_lds ? 3 : 4)
                     : mseg           ? 20
                                      : (pre ? (rsg ? 5 : 2) : rsg ? 4 : seg ? 3 : (in_lds ? 1 : 0)) + (mf ? 6 : 0);
@@ -1910,7 +2168,10 @@ static int32_t launch_wave(const pds_stft_plan *plan, const BatchArgs &a) {
 int32_t launch_stft_fast_f32(const pds_stft_plan *plan, const BatchArgs &a) {
   const int rows = plan->fast.rows;
 #ifdef PDS_DEV_ONLY512  // (ISA inspection builds: the headline instantiations alone)
-  if (plan->fast.kind == 512 && rows <= 25) return launch_wave<32, 16, 25, 4>(plan, a);
+#ifndef PDS_DEV_MINW
+#define PDS_DEV_MINW 4
+#endif
+  if (plan->fast.kind == 512 && rows <= 25) return launch_wave<32, 16, 25, PDS_DEV_MINW>(plan, a);
   set_error("stft_batch: development build");
   return PDS_ERR_INVALID;
 #else
@@ -2244,6 +2505,19 @@ int32_t fast_tables_create(pds_stft_plan *plan, const double *window, const int3
   if (rc == PDS_OK) rc = upload(&ft.d_ell_woff, ell_woff.data(), ell_woff.size());
   if (rc == PDS_OK) rc = upload(&ft.d_window, win.data(), win.size());
   if (rc == PDS_OK) rc = upload(&ft.d_twiddle, tw.data(), tw.size());
+  if (PDS_EXPERIMENTS && n1 == 32 && n2 == 16) {
+    // prefetch instantiations: window times 1/2 and the twiddle seeds W_N^r, W_N^4r, W_N^8r (see twiddle_chain15)
+    std::vector<float> wh(win), seed((size_t)n2 * 6);
+    for (float &v : wh) v *= 0.5f;
+    for (int r = 0; r < n2; ++r)
+      for (int j = 0; j < 3; ++j) {
+        const double ang = -2.0 * M_PI * (double)((r * (j == 0 ? 1 : 4 * j)) % N) / (double)N;
+        seed[((size_t)r * 3 + j) * 2 + 0] = (float)std::cos(ang);
+        seed[((size_t)r * 3 + j) * 2 + 1] = (float)std::sin(ang);
+      }
+    if (rc == PDS_OK) rc = upload(&ft.d_win_half, wh.data(), wh.size());
+    if (rc == PDS_OK) rc = upload(&ft.d_tw_seed, seed.data(), seed.size());
+  }
   std::vector<float> tws((size_t)n2 * 2);
   for (int r = 0; r < n2; ++r) {
     const double ang = -2.0 * M_PI * (double)r / (double)(2 * n2);
@@ -2295,6 +2569,8 @@ void fast_tables_destroy(pds_stft_plan *plan) {
   (void)hipFree(ft.d_window);
   (void)hipFree(ft.d_twiddle);
   (void)hipFree(ft.d_tw_special);
+  (void)hipFree(ft.d_win_half);
+  (void)hipFree(ft.d_tw_seed);
   (void)hipFree(ft.d_mf_tab);
   (void)hipFree(ft.d_rs_w);
   (void)hipFree(ft.d_ms_w);
