@@ -33,6 +33,10 @@ extern "C" {
 
 /* library version, major * 10000 + minor * 100 + patch */
 int32_t pds_version(void);
+/* 1 when the library was built with -DPDS_EXPERIMENTS=1: measured-and-rejected kernel forms (matrix-pipe front
+ * end, N = 1024 as 32 x 32, sample prefetch) are present and selectable through their environment variables;
+ * 0 in the product build, where those variables are ignored */
+int32_t pds_build_experiments(void);
 /* message describing the last error on this thread ("" if none) */
 const char *pds_last_error(void);
 /* number of visible HIP devices (0 when there is none; never fails) */

@@ -88,6 +88,7 @@ _CMVN_ROWS_ARGS = [
 # name -> (restype, argtypes); every symbol include/pds_amd.h declares
 SIGNATURES = {
     "pds_version": (c_int32, []),
+    "pds_build_experiments": (c_int32, []),
     "pds_last_error": (c_char_p, []),
     "pds_device_count": (c_int32, []),
     "pds_stft_plan_create": (

@@ -1,1842 +1,20 @@
-// Fused STFT filter-bank kernel for power-of-two DFT sizes 128..2048 (float32), gfx950.
-//
-// Every wavefront works alone -- no workgroup barrier in the steady state, no batch buffer.
-// A wave takes 64/N2 consecutive frames of one utterance (N2 lanes per frame) and does:
-//
-//  1. load: lane n2 of a frame's lane group reads the samples x[N2*n1 + n2] straight from
-//     global memory into registers (one 64-bit lane pointer + immediate offsets).  Frames
-//     that touch an end of the signal take a rolled gather that resolves numpy's
-//     "symmetric" reflection in the index (compute.py:599-600).
-//  2. window (v_mul_legacy_f32) and an in-lane REAL DFT of size N1 = N / N2 over n1
-//     (fft_inlane.h; the zero-padded tail rows are literal zeros, so the FFT is pruned).
-//  3. outputs k1 = 1..N1/2-1 are multiplied by the per-lane twiddles W_N^(n2*k1) and written
-//     to the wave's private LDS exchange area, transposed; lane k1 reads column k1 (N2
-//     complex values), runs an in-lane complex FFT of size N2 and holds the bins
-//     k1 + N1*k2.  Bins beyond N/2 mirror bins below it and only |X|^2 is needed, so the
-//     (N1/2 - 1) * N2 column bins plus the N2 + 1 multiples of N1/2 (a real DFT of the lanes'
-//     even/odd sample sums, done by lane 0 of the group) are exactly the half spectrum.
-//  4. |X|^2 (or |X|) of the wave's frames goes to its LDS area again (P[frame][bin], aliased
-//     over the exchange area) and the same lanes integrate the filters: lane (frame, j) owns
-//     every N2-th filter of the length-sorted list (ELL layout: slot s of lane j is filter
-//     order[s*N2 + j]; rows are dense bin ranges starting on a multiple of 4 bins, so both
-//     the weights and the powers arrive as 16-byte LDS reads), applies log() and stores.
-//
-// 9..18 KB of LDS per wave and <= 128 VGPRs (N <= 512) give 16 resident waves per CU.
-// Reference semantics: compute_full framing (compute.py:574-607) and _compute_frame
-// (compute.py:388-460), float32 arithmetic (the north star's 1e-4 tolerance).
-//
-// Measured alternatives are recorded in DESIGN.md (batch kernel with workgroup barriers and a
-// lane = frame filter phase: 0.76 G frames/s; this design: 2.2 G frames/s on one MI355X).
-#include <algorithm>
-#include <atomic>
-#include <cmath>
-#include <cstdio>
-#include <cstdlib>
-#include <cstring>
-#include <type_traits>
-#include <vector>
-
-#include "fft_inlane.h"
-#include "mfma_front.h"
-#include "rseg_tables.h"
-#include "mseg_tables.h"
-#include "pds_internal.h"
+// Fused STFT filter-bank path, host side: the plan's tables for the kernel of stft_wave_kernel.h
+// (fast_tables_create), the dispatch over the instantiated geometries (stft_geoms.def, one object file each:
+// stft_geom.hip) and the small helper kernels.
+#include "stft_wave_kernel.h"
 
 namespace pds {
 
-// Timing-only builds (tools/build_variant.sh -DPDS_ABLATE=mask) drop one stage each to see what it
-// costs; results are wrong by construction.  0 in the product build.
-// Wave priority per phase of an item (s_setprio): the four waves of a SIMD run the same sequence
-// of phases, and with equal priorities the issue arbiter lets them drift into the same phase, where
-// they queue for one unit (VALU in the transforms, LDS in the exchange and the filter walk) while
-// the other idles.  Raising the priority as an item ages ("oldest first": loads and the in-lane
-// real DFT 0, exchange and N2-point FFT 1, power spectrum + P stores 2, filter walk 3) keeps the
-// waves staggered: +10 % on the headline workload, +5 ... 10 % on every other geometry with more
-// than one wave per SIMD (tools/ab_libs.sh; flat priorities for the memory phases alone: +7 %,
-// youngest first: +3 %).  One hex digit per phase in PDS_PRIO_PACK, from the lowest digit:
-// 0 record + sample loads, 1 LDS exchange, 2 power spectrum + P stores, 3 filter walk,
-// 4 window + in-lane real DFT, 5 N2-point FFT.  Negative: no hints (tools/build_variant.sh).
-// (Round 2, with the row-segment walk: record + sample loads at priority 2 instead of 0 -- a wave gets its 25
-// loads out at once and waits for them, instead of queueing for issue slots first -- headline +2.5 % on two
-// boxes, Gabor-64 +2.3 %, the other geometries +-0: 0x103212.)
-#ifndef PDS_PRIO_PACK
-#define PDS_PRIO_PACK 0x103212
-#endif
-#if PDS_PRIO_PACK == 0xffffff  // (experiment: scheduling barriers at the phase boundaries, no priorities)
-#define PDS_PHASE(i) __builtin_amdgcn_sched_barrier(0)
-#else
-#define PDS_PHASE(i) do { if (PDS_PRIO_PACK >= 0) __builtin_amdgcn_s_setprio(((PDS_PRIO_PACK) >> (4 * (i))) & 3); } while (0)
-#endif
-#ifndef PDS_ABLATE
-#define PDS_ABLATE 0
-#endif
-// Diagnostic builds (tools/build_variant.sh -DPDS_STAMPS=1, tools/phase_stamps.py): every wave adds up
-// the shader-clock time it spends in each phase of an item (s_memtime at the phase boundaries, with
-// the loads drained where a phase ends at their arrival) and leaves the sums in a buffer set through
-// pds_debug_set_stamp_buffer.  The stamps themselves cost ~10 %; 0 in the product build.
-#ifndef PDS_STAMPS
-#define PDS_STAMPS 0
-#endif
 #if PDS_STAMPS
-static unsigned long long *g_stamp_buf = nullptr;
+unsigned long long *g_stamp_buf = nullptr;
 extern "C" __attribute__((visibility("default"))) void pds_debug_set_stamp_buffer(unsigned long long *d_buf) {
   g_stamp_buf = d_buf;
 }
-// (PDS_STAMPS=2: a wave's entry, loop start, loop end and item count only -- no stamps inside the loop, so the
-// build runs like the product; tools/wave_spread.py reads how evenly the waves finish)
-#define PDS_STAMP(i, drain)                                               \
-  do {                                                                    \
-    if (PDS_STAMPS == 2) break;                                           \
-    __builtin_amdgcn_sched_barrier(0);                                    \
-    if (drain) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           \
-    const unsigned long long now_ = __builtin_readcyclecounter();         \
-    st_acc[i] += now_ - st_prev;                                          \
-    st_prev = now_;                                                       \
-    __builtin_amdgcn_sched_barrier(0);                                    \
-  } while (0)
-#else
-#define PDS_STAMP(i, drain) do { } while (0)
 #endif
-// Experiment (tools/build_variant.sh -DPDS_STAGGER=1): the second half of a workgroup's waves (the SIMD
-// partners of the first half) runs half an item behind, held there by two workgroup barriers per item,
-// so that one partner's transform phase runs beside the other's filter phase.
-#ifndef PDS_STAGGER
-#define PDS_STAGGER 0
-#endif
-// Experiment (-DPDS_NT_STORE=1 | 2): non-temporal stores of the fused-deltas rows (1) and of the row-segment
-// walk's coefficients (2)
-#ifndef PDS_NT_STORE
-#define PDS_NT_STORE 0
-#endif
-// filter-walk depth of the geometries that run two waves per SIMD or fewer (256 registers and more)
-// (measured, tools/ab_libs.sh: segmented walk four steps deep at N = 1024, Gammatone-64 +3 %; ELL walk four
-// steps deep: N = 4096 +0.6 %, N = 2048 -0.5 %)
-#ifndef PDS_SEG_DEEP_N
-#define PDS_SEG_DEEP_N 1024
-#endif
-#ifndef PDS_ELL_DEEP_N
-#define PDS_ELL_DEEP_N 4096
-#endif
-// transform sizes from which dense banks take the matrix-pipe segment walk by default
-#ifndef PDS_MSEG_MIN_N
-#define PDS_MSEG_MIN_N 1024
-#endif
-#ifndef PDS_PAIR_SPLIT  // (N = 4096: a column's 64-point transform over a lane pair; 0: the lower half of the wave alone)
-#define PDS_PAIR_SPLIT 1
-#endif
-#ifndef PDS_N4096_MINW  // (waves per SIMD the 38-row N = 4096 instantiation is built for: with the pair split it needs 270 registers, i.e. 15 spilled dwords at two waves per SIMD, measured +19 % over one)
-#define PDS_N4096_MINW 2
-#endif
-#ifndef PDS_FAST_PROLOGUE  // (tables and wave areas set up 16 bytes at a time)
-#define PDS_FAST_PROLOGUE 1
-#endif
-#ifndef PDS_MSEG_RED4  // (experiment: the partial sums of the matrix-pipe walk read four at a time)
-#define PDS_MSEG_RED4 1
-#endif
-#ifndef PDS_FILTER_UNROLL
-#define PDS_FILTER_UNROLL 2
-#endif
-// PF instantiations (the next item's samples prefetched into registers, see the kernel):
-// PDS_PF_TW   inter-stage twiddles: 0 thirty registers (as without PF), 1 regenerated per item from three seeds
-// PDS_PF_WIN  window slice: 0 registers, 1 re-read from an LDS table per item (16-byte reads)
-// PDS_PF_PLACE where the prefetch loads are issued: 0 behind the exchange (in front of the column transforms),
-//             1 in front of the filter walk
-// PDS_PF_ILV  vector instructions the scheduler is asked to put between two prefetch loads (0: its own choice)
-// Round-3 experiments, measured and NOT in the product build (profiles/r3a_*.txt):
-// -DPDS_EXPERIMENTS=1 builds the prefetch instantiation (PF) and its tables, -DPDS_DYN=1 the dynamic item
-// distribution inside a workgroup (DYN); tools/ab_pf.sh and tools/ab_dyn.sh run the comparisons.
-#ifndef PDS_EXPERIMENTS
-#define PDS_EXPERIMENTS 0
-#endif
-#ifndef PDS_DYN
-#define PDS_DYN 0
-#endif
-#ifndef PDS_PF_TW
-#define PDS_PF_TW 1
-#endif
-#ifndef PDS_PF_WIN
-#define PDS_PF_WIN 0
-#endif
-#ifndef PDS_PF_PLACE
-#define PDS_PF_PLACE 0
-#endif
-#ifndef PDS_PF_WINAT  // (WINLDS: the window slice is re-read 0 inside a walk round, behind its reads, 1 behind the rounds)
-#define PDS_PF_WINAT 1
-#endif
-#ifndef PDS_PF_ILV
-#define PDS_PF_ILV 0
-#endif
-__device__ __forceinline__ void keep_alive(float v) { asm volatile("" ::"v"(v)); }
 
-struct FastParams {
-  const void *sig;  // TIN samples
-  const int64_t *offsets, *lengths, *nframes, *row_off;
-  void *out;  // TOUT features
-  int64_t out_stride;
-  const float *win_lane;    // [N2][N1]   window[N2*n1 + n2], zero beyond L
-  const float2 *tw_lane;    // [N2][N1/2] W_N^(n2*k1), pre-scaled (see rdft_scaled)
-  const float2 *tw_special; // [N2] e^{-2 pi i r / (2 N2)}
-  const float *win_half;    // PF: [N2][N1] the window times 1/2 (see twiddle_seeds)
-  const float2 *tw_seed;    // PF: [N2][3] W_N^(n2), W_N^(4 n2), W_N^(8 n2), unscaled
-  const float *ell_w;       // per slot: [N2][len + 4] dense weight rows (row j = lane j's filter)
-  const int32_t *ell_meta;  // [slots][N2] first bin of the row | (filter + 1) << 16
-  const int32_t *ell_len;   // [slots] row length in bins (multiple of 8)
-  const int32_t *ell_woff;  // [slots] start of the slot's rows inside ell_w (floats)
-  int ell_wfloats, ell_slots, ell_meta_pad, ell_meta_ints;  // meta_pad: ints in LDS, multiple of 4; meta_ints: valid ones
-  // segmented filter walk (dense banks, 16-lane frames; see the kernel): when seg_rounds > 0,
-  // ell_w / ell_meta hold its tables instead -- weights [slot][seg_len + 4], then in ell_meta the
-  // slots' first bins [seg_rounds * 64] followed by (first slot | segments << 16) per filter
-  int seg_rounds, seg_len, num_filts;
-  int L, S, pad_left, include_energy, use_power, use_log;
-  float log_floor, inv_L, preemph;
-  double preemph_d;  // the coefficient at full precision (float64 samples)
-  int chunks_per_utt, num_utts;
-  int waves;  // wavefronts per workgroup of this launch (<= MAXWAVES)
-  unsigned waves_rcp;  // ceil(2^32 / waves): ticket / waves as a multiply-high (tickets < 2^28)
-  int lds_ticket_off;  // floats from the start of the workgroup's LDS to its ticket counter
-  int dyn;             // items handed out by the workgroup's ticket counter (0: static round-robin)
-  const float *mf_tab;  // matrix-pipe front end (MF instantiations): image of MfmaFrontTables
-  unsigned long long *stamps;  // diagnostic builds (PDS_STAMPS): [grid waves][12] phase times and absolute times, else null
-  // fused statics + deltas launches (DLT instantiations): every wave walks ONE contiguous stretch of the
-  // batch's chunks and keeps the statics of the last three chunks in registers (see the kernel)
-  const int64_t *chunk_prefix;  // [num_utts + 1] chunks in front of every utterance (chunk_prefix_kernel)
-  int dl_inner;                 // coefficients per frame (= num_coeffs): order k goes to columns [k C, (k + 1) C)
-  int dl_debug;                 // measurement switches (PDS_DL_DEBUG): 1 no delta stores, 2 no deltas at all, 4 no statics stores
-  int dl_eslot;                 // round * 64 + lane of a lane without a filter: carries the energy (-1: none)
-  float dl_f1[5], dl_f2[9];     // taps of order 1 and order 2 (context window 2), correlation order
-  int step_utts, step_chunks;  // (grid waves) / chunks_per_utt and (grid waves) % chunks_per_utt
-};
-
-// v_mul_legacy_f32: IEEE multiply except that 0 * x = 0 for every x (NaN and Inf included)
-__device__ __forceinline__ float mul_legacy(float x, float y) {
-  float z;
-  asm("v_mul_legacy_f32 %0, %1, %2" : "=v"(z) : "v"(x), "v"(y));
-  return z;
-}
-
-// DPP row_shr:M of `src` into `old`: lane i of a 16-lane row takes src of lane i - M; lanes whose
-// source would lie outside the row keep `old`
-template <int M>
-__device__ __forceinline__ float dpp_row_shr_keep(float old, float src) {
-  return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(src),
-                                                    0x110 + M, 0xf, 0xf, false));
-}
-
-// natural log as v_log_f32 (log2, 1 ulp) times ln 2.  The argument is never below the plan's log
-// floor, which plan creation requires to be a normal float for this kernel, so the denormal
-// rescue sequence of the library logf is dead weight (12 instructions per value).
-__device__ __forceinline__ float fast_log(float x) {
-  return __builtin_amdgcn_logf(x) * 0.69314718055994530942f;
-}
-
-// Load through the constant address space: tables and utterance records are never written by
-// this kernel, and a uniform address then always becomes a scalar load (the compiler otherwise
-// falls back to 64-lane vector loads wherever it cannot prove that no store precedes the load).
-typedef int Int4 __attribute__((ext_vector_type(4)));
-template <typename T>
-__device__ __forceinline__ T load_const(const T *ptr) {
-  typedef const T __attribute__((address_space(4))) *const_ptr;
-  return *(const_ptr)(uintptr_t)ptr;
-}
-
-// x + (x of the lane selected by a DPP control word within the row)
-template <int CTRL>
-__device__ __forceinline__ float dpp_add(float x) {
-  return x + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xf, 0xf, false));
-}
-
-__device__ __forceinline__ void wave_sync() {
-  // LDS operations of one wave execute in order; this only stops the compiler from moving
-  // memory operations across the hand-off between lanes
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
-
-// N = N1 * N2: in-lane real DFT size x lanes per frame.  NROWS = ceil(L / N2) rows of N2
-// samples per frame, a compile-time constant so that the zero-padded tail is literal zeros.
-// N1 is a power of two (N = 128 .. 2048, radix-2 network) or, for transforms without zero
-// padding (pad_to_nearest_power_of_two = False: N = L = 160, 200, 240, 320, 400, 480, 640, 800,
-// 960), one of 20, 25, 30 evaluated directly; N2 is always a power of two.
-template <int N1, int N2, int NROWS>
-struct WaveGeom {
-  static constexpr int N = N1 * N2;
-  static constexpr int NREG = (N1 - 1) / 2;  // step-2 outputs that become regular columns: k1 = 1..NREG
-  static constexpr int COLS = NREG + 1;     // + column 0: the real-valued outputs (k1 = 0, and N1/2 if even)
-  static constexpr int CPL = (COLS + N2 - 1) / N2;  // step-3 columns per lane
-  static constexpr bool FULL = COLS % N2 == 0;      // every lane owns CPL columns (powers of two)
-  // the packed real column (multiples of N1/2) is untangled by lanes 0..N2/2, one bin pair each
-  static constexpr bool DIST = N2 >= 16;
-  static constexpr int GROUPS = 64 / N2;    // frames per wave iteration
-  static constexpr int NB = N / 2 + 1;      // half-spectrum bins
-  static constexpr int RS = N2 + 2;         // exchange row stride (float2): conflict-free
-  static constexpr int EXCH_F2 = GROUPS * COLS * RS;  // float2 per wave
-  // P row stride: >= NB + 1 (energy) and = 16 (mod 32) so that the two frames sharing a
-  // 32-lane half write to disjoint banks
-  static constexpr int PSTR = ((NB + 1 + 15) / 32) * 32 + 16;
-  static_assert(GROUPS * PSTR <= EXCH_F2 * 2, "P must fit over the exchange area");
-  static_assert(EXCH_F2 * 2 >= 64 * NROWS, "edge-frame gather reuses the exchange area");
-  static_assert(N % 2 == 0 && CPL >= 1 && N2 <= 64 && (RS * 8) % 16 == 0, "geometry");
-  // (N = 4096 = 64 x 64 has 32 columns for 64 lanes: the upper half of the wave idles in step 3)
-  static_assert(inl::is_pow2(N1) ? (FULL || N2 == 2 * COLS) : 600 % N1 == 0,
-                "in-lane DFT sizes: 2^k, or a divisor of 600");
-  static_assert(NROWS <= N1 && NROWS > 0, "rows");
-};
-
-// ELL_LDS: the filter weight rows are staged in LDS (else read from global memory through L1/L2)
-// PRE: pre-emphasis x[i] - c x[i-1] (reference pre.py:146) applied while loading the frame
-// MAXWAVES / MINW: launch bounds (workgroup size limit, waves per SIMD the register budget must
-// allow); the actual workgroup size is chosen per launch from the LDS the filter table needs
-// filter slots handled by the unrolled slot loop: their row lengths and table offsets arrive with
-// two 16-byte scalar loads per item; banks with more than USLOTS * N2 filters run the remaining
-// slots from memory one by one
-constexpr int USLOTS = 4;
-
-// SEG: the filter phase is the segmented walk for dense banks (its own instantiation: inside the
-// ELL kernel its registers cost the headline instantiation three spills)
-//
-// MF > 0: steps 1-3a (loads, window, N1-point real DFT) in the matrix-pipe form of mfma_front.h with
-// MF pair steps: a lane holds k-slot q = lane / 16 of every frame's 16 x 16 x 4 tiles instead of
-// one frame's samples, the N1-point DFT costs 2 (MF + 1) v_mfma_f32_16x16x4_f32 per frame on the
-// matrix pipe (which runs beside the vector pipe) instead of ~250 vector instructions per item, and
-// the lane twiddles and stores four output rows of each frame.  From the exchange on the kernel is
-// the same.  (16-lane geometries with N1 = 32.)
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-
-//
-// RSG: the filter phase is the row-segment walk of rseg_tables.h (power spectra bin-major in LDS,
-// a lane = one segment of one filter for all four frames; 16-lane geometries, tables in LDS)
-//
-// TIN / TOUT: sample and feature types in memory.  The arithmetic is float32 whatever they are:
-// float64 samples are rounded as the frame is loaded (pre-emphasis, if fused, before the rounding, in
-// float64 like the reference's own pass), float64 features are widened at the store -- the dtype flow
-// of the reference's drivers (float64 audio in, compute.py:601 output dtype = input dtype) without
-// separate conversion passes over the signal and the features.
-template <int N1, int N2, int NROWS, int MAXWAVES, int MINW, bool ELL_LDS, bool PRE, int SEG = 0, int MF = 0,
-          bool RSG = false, typename TIN = float, typename TOUT = float, int DLT = 0, bool STR = false, bool PF = false>
-__global__ __launch_bounds__(MAXWAVES * 64, MINW) void stft_wave_kernel(const FastParams p) {
-  // PF: the NEXT item's samples are loaded into registers while this item's column transforms and filter
-  // walk run (a wave's own frame loads -- issue and wait -- were 27 % of its item, profiles/r2b_phase_stamps.txt).
-  // The registers come from the inter-stage twiddles: instead of thirty loop-invariant registers the lane keeps
-  // three seeds W^r, W^4r, W^8r and regenerates W^(r k1), k1 = 1..15, per item by twelve complex products at
-  // most four deep (twiddle_chain; tests/test_twiddle_chain.py replays it against float64).  The next item's
-  // utterance record is fetched at the top of the item for that.
-  static_assert(!PF || (DLT == 0 && !STR && MF == 0 && !PRE && std::is_same<TIN, float>::value && N1 == 32 && N2 == 16),
-                "prefetch: 32 x 16 geometry, float32 samples, round-robin scheduling");
-  // STR: the stretch scheduling of the DLT launches without their deltas -- every wave walks one contiguous
-  // stretch of the batch's EXISTING chunks (chunk_prefix) -- for ragged batches: dealt round-robin over
-  // (utterance, chunk < chunks of the longest) the waves skip the chunks short utterances do not have and end
-  // up with unequal shares (lengths uniform in 1 ... 15 s: 9 % slower per frame than equal lengths).
-  constexpr bool STRETCH = DLT > 0 || STR;
-  static_assert(!(STR && DLT > 0), "stretch scheduling is part of the fused-deltas launches already");
-  // DLT = K > 0: Deltas(K, context_window 2, edge padding) of the features appended to every row by the
-  // same launch (reference post.py:462-491; BASELINE.json configs[2]).  Every wave walks ONE contiguous
-  // stretch of the batch's chunks (chunk_prefix: the utterances' chunk counts summed up by a small
-  // kernel in front, so ragged batches are dealt evenly too) plus one halo chunk in front of and
-  // behind every piece of an utterance inside it, and keeps the logged coefficients of the last two
-  // chunks in registers: in the row-segment walk a filter's four frames end up in ONE lane, so with
-  // the chunk just computed a lane holds twelve consecutive frames of its filter -- the reach of the
-  // order-2 taps around the middle chunk, whose deltas it then forms in float32 (the reference
-  // accumulates in float64 and rounds: |difference| of a few float32 ulps of the statics, inside the
-  // feature tolerance) and stores.  No static is read back from memory, no second kernel; the price is
-  // three waves per SIMD instead of four (the window registers) and ~14 multiply-adds per delta.  The
-  // energy column has no filter lane: a spare lane of the walk (dl_eslot) collects the four frames'
-  // energies and differentiates them like a filter.
-  static_assert(DLT == 0 || (DLT <= 2 && N2 == 16 && RSG && !PRE && std::is_same<TOUT, float>::value &&
-                             std::is_same<TIN, float>::value && MF == 0),
-                "fused deltas: order 1 or 2, row-segment walk, float32 samples and features");
-  static_assert(MF == 0 || std::is_same<TIN, float>::value, "matrix-pipe front end: float32 samples");
-  using G = WaveGeom<N1, N2, NROWS>;
-  constexpr int N = G::N, COLS = G::COLS, NREG = G::NREG, RS = G::RS, NB = G::NB, PSTR = G::PSTR;
-  constexpr int MSLOTS = 2 * MF + 1;  // per-lane sample slots of a frame (MF)
-  static_assert(MF == 0 || (N2 == 16 && N1 == 32 && MF == mfma_front_steps(NROWS)), "matrix-pipe front end: 32 x 16");
-  static_assert(MF == 0 || 4 * MSLOTS * 64 <= G::EXCH_F2 * 2, "edge-frame gather reuses the exchange area");
-  constexpr int NBP = (NB + 3) / 4 * 4;  // RSG: bins kept in LDS (bin NBP = dump slot), as build_rseg sizes them
-  static_assert(!RSG || (G::GROUPS == 4 && ELL_LDS && !SEG && (NBP + 1) * 4 <= G::EXCH_F2 * 2),
-                "row-segment walk: four frames per wave, tables in LDS");
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int g = lane / N2, r = lane % N2;
-  // PAIR (float64 samples, 16 lanes per frame): the frame is loaded as 16-byte pairs of samples --
-  // an 8-byte load instruction of a wave costs the memory path as much as a 16-byte one
-  // (tools/vmem_microbench) -- so a lane receives residues 2s and 2s + 1 of one row, lanes 0..7 of the
-  // even rows, lanes 8..15 of the odd ones; lane s and lane s + 8 then swap one sample of every pair
-  // (a masked row_ror:8 each way) and lane s owns residue 2s, lane s + 8 residue 2s + 1 of EVERY row.
-  // `rho` is the residue (n2) whose samples, window and twiddles the lane holds until the exchange;
-  // it is `r` everywhere else.
-  constexpr bool PAIR = !std::is_same<TIN, float>::value && N2 == 16 && MF == 0;
-  const int rho = PAIR ? ((r & 7) * 2 + (r >> 3)) : r;
-  constexpr int LOADSPAN = PAIR ? (NROWS + 1) / 2 * 32 : NROWS * N2;  // samples a frame's direct loads reach over
-  [[maybe_unused]] const unsigned long long st_entry = PDS_STAMPS ? __builtin_readcyclecounter() : 0;
-  float *wbase = smem + wave * (G::EXCH_F2 * 2);
-  float2 *exch = reinterpret_cast<float2 *>(wbase) + g * COLS * RS;
-  float *Pg = wbase + g * PSTR;
-  // filter table -> LDS once per workgroup (read by every wave, every iteration): per-slot
-  // weight rows.  Tables too large for LDS (dense complex banks) stay in global memory and
-  // come through L1/L2.
-  const int nthreads = p.waves * 64;
-  float2 *sw_lds = reinterpret_cast<float2 *>(smem + p.waves * (G::EXCH_F2 * 2));  // [N2]
-  int *meta_lds = reinterpret_cast<int *>(sw_lds + N2);
-  float *ellw_lds = reinterpret_cast<float *>(meta_lds + p.ell_meta_pad);
-  constexpr bool TWCHAIN = PF && PDS_PF_TW == 1;  // twiddles regenerated per item; window times 1/2
-  constexpr bool WINLDS = PF && PDS_PF_WIN == 1;  // window slice re-read from LDS per item
-  constexpr int WSTR = ((NROWS + 3) & ~3) % 8 == 4 ? ((NROWS + 3) & ~3) : ((NROWS + 3) & ~3) + 4;  // row stride = 4 (mod 8) floats: conflict-free 16-byte reads
-  [[maybe_unused]] float *win_lds = ellw_lds + (ELL_LDS ? p.ell_wfloats : 0);  // [N2][WSTR]
-  if constexpr (WINLDS) {
-    const float *wsrc = TWCHAIN ? p.win_half : p.win_lane;
-    for (int i = threadIdx.x; i < N2 * WSTR; i += p.waves * 64) {
-      const int rr = i / WSTR, k = i - rr * WSTR;
-      win_lds[i] = k < NROWS ? wsrc[rr * N1 + k] : 0.0f;
-    }
-  }
-  if (threadIdx.x < N2) sw_lds[threadIdx.x] = p.tw_special[threadIdx.x];
-  // DYN: the workgroup's waves draw their items from one ticket counter in LDS instead of taking every
-  // (grid waves)-th item each.  The four waves of a SIMD do not run at the same pace (the issue arbiter
-  // prefers the older wave, and the priorities that keep them staggered add to it): with equal shares
-  // the waves of one CU finished between 430 000 and 500 000 cycles of a launch (tools/wave_spread.py),
-  // i.e. the last tenth of a launch ran on a draining CU.  Ticket t of workgroup w is item
-  // (t / waves) * (grid waves) + w * waves + t % waves -- the same items as before, so neighbouring
-  // waves still work on neighbouring chunks at about the same time -- and a wave fetches its next
-  // ticket (one ds_add_rtn) at the top of an item, a filter walk ahead of needing it.
-  constexpr bool DYN = PDS_DYN && !STRETCH && !PF;
-  [[maybe_unused]] int *ticket_lds = reinterpret_cast<int *>(smem + p.lds_ticket_off);
-  if constexpr (DYN) {
-    if (threadIdx.x == 0) *ticket_lds = p.waves;  // (tickets 0 .. waves - 1 are the waves' first items)
-  }
-  // (slots beyond the table read as "no filter": the unrolled slot loop fetches USLOTS entries)
-  for (int i = threadIdx.x; i < p.ell_meta_pad; i += nthreads)
-    meta_lds[i] = i < p.ell_meta_ints ? p.ell_meta[i] : 0;
-  // (16 bytes per thread and pass: every table is a multiple of four floats long and starts on 16 bytes, and
-  // so do the wave areas -- a launch's prologue is ~10 us of its ~270, and a pass of this loop a trip to L2)
-#if PDS_FAST_PROLOGUE
-  static_assert((G::EXCH_F2 * 2) % 4 == 0, "wave areas are zeroed 16 bytes at a time");
-  if constexpr (ELL_LDS) {
-    const float4 *src4 = reinterpret_cast<const float4 *>(p.ell_w);
-    float4 *dst4 = reinterpret_cast<float4 *>(ellw_lds);
-    for (int i = threadIdx.x; i < (p.ell_wfloats >> 2); i += nthreads) dst4[i] = src4[i];
-  }
-  // the wave areas start out zeroed so that never-written P padding is finite
-  {
-    float4 *z4 = reinterpret_cast<float4 *>(smem);
-    for (int i = threadIdx.x; i < p.waves * (G::EXCH_F2 * 2 / 4); i += nthreads) z4[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-  }
-#else
-  if constexpr (ELL_LDS)
-    for (int i = threadIdx.x; i < p.ell_wfloats; i += nthreads) ellw_lds[i] = p.ell_w[i];
-  // the wave areas start out zeroed so that never-written P padding is finite
-  for (int i = threadIdx.x; i < p.waves * G::EXCH_F2 * 2; i += nthreads) smem[i] = 0.0f;
-#endif
-  __syncthreads();
-
-  // per-lane constants, loop invariant: window slice and inter-stage twiddles (issued in front of the LDS
-  // set-up instead: measured slower, 0.0328 against 0.0308 ms at 64 utterances)
-  [[maybe_unused]] float win[(MF || WINLDS) ? 1 : NROWS];
-  [[maybe_unused]] float twr[(MF || TWCHAIN) ? 1 : COLS], twi[(MF || TWCHAIN) ? 1 : COLS];
-  [[maybe_unused]] float sd[6] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};  // TWCHAIN: the seeds W^r, W^4r, W^8r
-  // MF: window and byte offset of the lane's sample slots, A operands of the two chains, twiddles of
-  // the lane's four output rows
-  [[maybe_unused]] float mwin[MSLOTS], mare[MF + 1], maim[MF + 1], mtwr[4], mtwi[4];
-  [[maybe_unused]] unsigned moff[MSLOTS];
-  if constexpr (MF > 0) {
-    const float *tab = p.mf_tab;
-#pragma unroll
-    for (int sl = 0; sl < MSLOTS; ++sl) {
-      mwin[sl] = tab[sl * 64 + lane];
-      moff[sl] = (unsigned)reinterpret_cast<const int *>(tab)[(MSLOTS + sl) * 64 + lane] * 4u;
-    }
-#pragma unroll
-    for (int t = 0; t <= MF; ++t) {
-      mare[t] = tab[(3 * MSLOTS + t) * 64 + lane];
-      maim[t] = tab[(3 * MSLOTS + MF + 1 + t) * 64 + lane];
-    }
-#pragma unroll
-    for (int v = 0; v < 4; ++v) {
-      const float2 t = reinterpret_cast<const float2 *>(tab + (3 * MSLOTS + 2 * (MF + 1)) * 64)[v * 64 + lane];
-      mtwr[v] = t.x;
-      mtwi[v] = t.y;
-    }
-  } else {
-    if constexpr (!WINLDS) {
-      const float *wsrc = TWCHAIN ? p.win_half : p.win_lane;
-#pragma unroll
-      for (int n1 = 0; n1 < NROWS; ++n1) win[n1] = wsrc[rho * N1 + n1];
-    }
-    if constexpr (TWCHAIN) {
-#pragma unroll
-      for (int j = 0; j < 3; ++j) {
-        const float2 t = p.tw_seed[rho * 3 + j];
-        sd[2 * j] = t.x;
-        sd[2 * j + 1] = t.y;
-      }
-    } else {
-#pragma unroll
-      for (int k1 = 1; k1 <= NREG; ++k1) {
-        const float2 t = p.tw_lane[rho * COLS + k1];
-        twr[k1] = t.x;
-        twi[k1] = t.y;
-      }
-    }
-  }
-  // PF: the next item's samples (in flight from the middle of an item to the top of the next) and whether
-  // they are the next item's at all (a regular item: all frames exist, every row inside the signal)
-  [[maybe_unused]] float pfv[PF ? NROWS : 1];
-  // WINLDS: the window slice lives in registers from the end of an item's filter walk to the top of the next item
-  // only (read from the LDS table behind the walk's own reads, so that the round trip is not the first thing an
-  // item waits for); the column transforms, where the registers are scarce, run without it
-  [[maybe_unused]] float wl[WINLDS ? NROWS : 1];
-  [[maybe_unused]] auto read_window = [&]() {
-    if constexpr (WINLDS) {
-      const float4 *w4 = reinterpret_cast<const float4 *>(win_lds + rho * WSTR);
-#pragma unroll
-      for (int j = 0; j < (NROWS + 3) / 4; ++j) {
-        const float4 w = w4[j];
-        const float wv[4] = {w.x, w.y, w.z, w.w};
-#pragma unroll
-        for (int u = 0; u < 4; ++u)
-          if (4 * j + u < NROWS) wl[4 * j + u] = wv[u];
-      }
-    }
-  };
-  read_window();
-  [[maybe_unused]] bool pf_ready = false;
-  [[maybe_unused]] const int pf_lane = __mul24(g, p.S) + r;  // the lane's first sample inside an item's stretch
-  const int L = p.L, S = p.S;
-  const bool use_power = p.use_power != 0;
-  const int col0 = p.include_energy ? 1 : 0;
-
-  // work items: (utterance, chunk of GROUPS consecutive frames), dealt round-robin to all waves
-  // of the grid: the waves of a workgroup take neighbouring chunks, so overlapping samples are
-  // shared through the CU's L1.  The step to a wave's next item is a precomputed (utterances,
-  // chunks) pair -- scalar instructions compete with vector ones for issue slots, so the
-  // bookkeeping per item is kept to a handful of them.
-  int b = 0;
-  // Workgroups are handed to the 8 XCDs round-robin (workgroup i runs on XCD i % 8, each with its
-  // own L2): renumber them so that an XCD's workgroups take neighbouring chunks and the samples
-  // two neighbours share (L - S per frame) are fetched into one L2 instead of two.
-  int wg = blockIdx.x;
-#ifndef PDS_NO_XCD_MAP
-  if ((gridDim.x & 7) == 0) wg = (wg & 7) * (gridDim.x >> 3) + (wg >> 3);
-#endif
-  int chunk = wg * p.waves + wave;
-  if constexpr (!STRETCH) {
-    while (chunk >= p.chunks_per_utt && b < p.num_utts) {  // once per kernel
-      chunk -= p.chunks_per_utt;
-      ++b;
-    }
-  }
-  // DYN: (rb, rc) = utterance and chunk of the workgroup's first item of round `rnd` (items
-  // rnd * (grid waves) + wg * waves + 0 .. waves - 1); a wave moves it forward to its ticket's round
-  [[maybe_unused]] int rnd = 0, rb = 0, rc = wg * p.waves;
-  if constexpr (DYN) {
-    while (rc >= p.chunks_per_utt && rb < p.num_utts) {
-      rc -= p.chunks_per_utt;
-      ++rb;
-    }
-  }
-  // sets (b, chunk) to ticket t's item; b >= num_utts: no such item (and none for any later ticket)
-  [[maybe_unused]] auto take_ticket = [&](const int t) {
-    const int jn = (int)__umulhi((unsigned)t, p.waves_rcp), o = t - jn * p.waves;
-    while (rnd < jn && rb < p.num_utts) {  // (one step per item taken in the steady state)
-      rc += p.step_chunks;
-      rb += p.step_utts;
-      if (rc >= p.chunks_per_utt) {
-        rc -= p.chunks_per_utt;
-        ++rb;
-      }
-      ++rnd;
-    }
-    b = rb;
-    chunk = rc + o;
-    while (chunk >= p.chunks_per_utt && b < p.num_utts) {
-      chunk -= p.chunks_per_utt;
-      ++b;
-    }
-  };
-  [[maybe_unused]] int ticket_v = 0;  // lane 0: the wave's next ticket, in flight from the top of an item
-  [[maybe_unused]] auto fetch_ticket = [&]() {
-    if (lane == 0) ticket_v = __hip_atomic_fetch_add(ticket_lds, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-  };
-  // the next item's (b, chunk) and its utterance record
-  [[maybe_unused]] auto next_item_dyn = [&](int &nfr_, int &n_, int64_t &sig_off_, int64_t &out_row_) {
-    const int last_b = b;
-    take_ticket(__builtin_amdgcn_readfirstlane(ticket_v));
-    const int pb_ = b < p.num_utts ? b : last_b;  // (any valid record past the end)
-    nfr_ = (int)load_const(p.nframes + pb_);
-    n_ = (int)load_const(p.lengths + pb_);
-    sig_off_ = load_const(p.offsets + pb_);
-    out_row_ = load_const(p.row_off + pb_);
-  };
-  // The utterance record of an item (frame count, length, signal offset, output row) is fetched
-  // during the filter phase of the item before: four dependent scalar-load round trips at the
-  // top of every item otherwise.
-  int nfr = 0, n = 0;
-  int64_t sig_off = 0, out_row = 0;
-  if (!STRETCH && b < p.num_utts) {
-    nfr = (int)load_const(p.nframes + b);  // (frame and sample counts fit an int: host check)
-    n = (int)load_const(p.lengths + b);
-    sig_off = load_const(p.offsets + b);
-    out_row = load_const(p.row_off + b);
-  }
-  // (DLT) the wave's stretch of the batch's chunks: `left` chunks still to emit starting with chunk
-  // e_lo of utterance b.  A PIECE is the part of one utterance inside the stretch, chunks [e_lo, e_hi):
-  // the wave computes chunks max(e_lo - 1, 0) .. min(e_hi, last chunk) (the first and the last one only
-  // for their statics: halos), stores the statics of the piece's chunks and, with chunk c computed,
-  // the deltas of chunk c - 1.  Frames in front of the utterance repeat its first frame, frames
-  // behind it the last one (post.py:447 "edge"); the lanes of a chunk's frames past the utterance's
-  // end compute the last frame again (see the loads), so the last chunk's window is already padded.
-  constexpr int DR = 2;  // row-segment rounds a fused-deltas launch may have (window registers per round)
-  [[maybe_unused]] int left = 0, e_lo = 0, e_hi = 0, c_last = -1;
-  [[maybe_unused]] bool piece_open = false, ran = false;
-  [[maybe_unused]] float Wp[DR][4], Wc[DR][4], e_keep = 0.0f;
-  if constexpr (STRETCH) {
-    const int gw = wg * p.waves + wave, GW = (int)gridDim.x * p.waves;
-    const int total = (int)load_const(p.chunk_prefix + p.num_utts);  // (fits an int: host check)
-    const int per = total / GW, rem = total - per * GW;
-    const int pos = gw * per + (gw < rem ? gw : rem);
-    left = per + (gw < rem ? 1 : 0);
-    // the utterance holding chunk `pos`: the last one whose prefix is <= pos (empty ones are skipped)
-    int lo = 0, hi = p.num_utts;  // prefix[lo] <= pos < prefix[hi] (when left > 0)
-    while (left > 0 && hi - lo > 1) {
-      const int mid = (lo + hi) >> 1;
-      if ((int)load_const(p.chunk_prefix + mid) <= pos) lo = mid; else hi = mid;
-    }
-    b = lo;
-    e_lo = left > 0 ? pos - (int)load_const(p.chunk_prefix + lo) : 0;
-    chunk = 0;
-#pragma unroll
-    for (int rd = 0; rd < DR; ++rd)
-#pragma unroll
-      for (int q = 0; q < 4; ++q) Wp[rd][q] = Wc[rd][q] = 0.0f;
-  }
-  // The rows of chunk `ce` of the utterance in hand, statics AND deltas, from the window (Wp, Wc, nx) =
-  // frames 4 ce - 4 .. 4 ce + 7: the lanes form the deltas of their coefficients, everything is put down
-  // row-major in the wave's LDS area (free between the filter walk and the next exchange) and leaves as
-  // ONE contiguous store per row, 16 bytes per lane.  (Stored straight from the lanes that hold them --
-  // a dword per lane and frame, some forty lanes per instruction, 25 instructions per item -- the
-  // stores alone cost a third of the launch: the vector memory path handles such an instruction lane
-  // by lane.)
-  [[maybe_unused]] auto emit_rows = [&](const int ce, const float (&nx)[DR][4]) {
-    if (p.dl_debug & 2) return;
-    const int C = p.dl_inner;
-    const int W = (DLT + 1) * C, WS = (W + 3) & ~3;  // row width, staged row stride (floats)
-    float *stage = wbase;
-    wave_sync();  // (the filter walk's reads of the area are done: same wave, in order)
-#pragma unroll
-    for (int rd = 0; rd < DR; ++rd) {
-      if (rd >= p.seg_rounds) break;
-      // the lane's column: its filter (first lane of a run), the energy (dl_eslot), or none: a dump slot
-      const int f = (meta_lds[rd * 64 + lane] >> 16) - 1;
-      const int col = f >= 0 ? col0 + f : (p.dl_eslot == rd * 64 + lane ? 0 : -1);
-      const float v[12] = {Wp[rd][0], Wp[rd][1], Wp[rd][2], Wp[rd][3], Wc[rd][0], Wc[rd][1],
-                           Wc[rd][2], Wc[rd][3], nx[rd][0], nx[rd][1], nx[rd][2], nx[rd][3]};
-      float *mine = stage + (col >= 0 ? col : 4 * WS + lane);
-      const int wrow = col >= 0 ? WS : 0, wk = col >= 0 ? C : 0;
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        float d = p.dl_f1[0] * v[q + 2];
-#pragma unroll
-        for (int t = 1; t < 5; ++t) d = fmaf(p.dl_f1[t], v[q + 2 + t], d);
-        mine[q * wrow] = v[4 + q];
-        mine[q * wrow + wk] = d;
-        if constexpr (DLT == 2) {
-          float dd = p.dl_f2[0] * v[q];
-#pragma unroll
-          for (int t = 1; t < 9; ++t) dd = fmaf(p.dl_f2[t], v[q + t], dd);
-          mine[q * wrow + 2 * wk] = dd;
-        }
-      }
-    }
-    wave_sync();
-    if (!(p.dl_debug & 1)) {
-      float *orow = static_cast<float *>(p.out) + (out_row + (int64_t)ce * 4) * p.out_stride;
-      const int fh = nfr - ce * 4;  // frames of the chunk that exist (>= 1)
-      const int full = W >> 2, tail = W & 3;
-      typedef float F4 __attribute__((ext_vector_type(4), aligned(4)));  // rows start on any float
-      if (fh >= 4 && full <= 64) {
-        // (the common case: four reads in flight, then four stores, one lane predicate)
-        const int l = lane < full ? lane : full - 1;
-        float4 val[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) val[q] = *reinterpret_cast<const float4 *>(stage + q * WS + 4 * l);
-        if (lane < full) {
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            F4 o = {val[q].x, val[q].y, val[q].z, val[q].w};
-#if PDS_NT_STORE & 1
-            __builtin_nontemporal_store(o, reinterpret_cast<F4 *>(orow + (int64_t)q * p.out_stride + 4 * l));
-#else
-            *reinterpret_cast<F4 *>(orow + (int64_t)q * p.out_stride + 4 * l) = o;
-#endif
-          }
-        }
-      } else {
-        for (int l0 = 0; l0 < full; l0 += 64) {
-          const int l = l0 + lane;
-          if (l < full) {
-#pragma unroll 1
-            for (int q = 0; q < 4; ++q)
-              if (q < fh) {
-                const float4 val = *reinterpret_cast<const float4 *>(stage + q * WS + 4 * l);
-                F4 o = {val.x, val.y, val.z, val.w};
-                *reinterpret_cast<F4 *>(orow + (int64_t)q * p.out_stride + 4 * l) = o;
-              }
-          }
-        }
-      }
-      if (tail) {  // the last W % 4 columns of the four rows: one dword store
-        const int q = tail == 1 ? lane : tail == 2 ? lane >> 1 : (lane * 11) >> 5;  // lane / tail where it is < 4
-        const int jj = lane - q * tail;
-        if (q < fh && q < 4) orow[(int64_t)q * p.out_stride + 4 * full + jj] = stage[q * WS + 4 * full + jj];
-      }
-    }
-    wave_sync();
-  };
-  if constexpr (PDS_STAGGER) {
-    if (b < p.num_utts && (wave & 4)) __builtin_amdgcn_s_barrier();
-  }
-  [[maybe_unused]] unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  [[maybe_unused]] unsigned long long st_prev = PDS_STAMPS ? __builtin_readcyclecounter() : 0;
-  [[maybe_unused]] const unsigned long long st_loop = st_prev;
-  while (STRETCH || b < p.num_utts) {
-    if constexpr (STRETCH) {
-      if (!piece_open) {
-        if (left <= 0) break;
-        nfr = (int)load_const(p.nframes + b);
-        const int chunks_b = (nfr + G::GROUPS - 1) / G::GROUPS;
-        if (e_lo >= chunks_b) {  // an utterance without frames (only the first piece starts past chunk 0)
-          ++b;
-          e_lo = 0;
-          continue;
-        }
-        n = (int)load_const(p.lengths + b);
-        sig_off = load_const(p.offsets + b);
-        out_row = load_const(p.row_off + b);
-        e_hi = e_lo + left < chunks_b ? e_lo + left : chunks_b;
-        // (DLT: one halo chunk on either side where the utterance has one; STR: the piece's own chunks)
-        c_last = DLT > 0 ? (e_hi < chunks_b ? e_hi : chunks_b - 1) : e_hi - 1;
-        chunk = DLT > 0 ? (e_lo > 0 ? e_lo - 1 : 0) : e_lo;
-        piece_open = true;
-        ran = false;
-      }
-      if constexpr (STR) {  // (the item of the pass before is done: on to the next chunk)
-        if (ran) ++chunk;
-        ran = true;
-      }
-      if (chunk > c_last) {
-        // the piece's chunks are computed.  Where it runs to the utterance's end the last chunk's deltas
-        // are still due: the frames behind it repeat the last frame, which is frame 3 of the last chunk
-        // whatever the frame count (see above)
-        if (DLT > 0 && c_last < e_hi) {
-          float nx[DR][4];
-#pragma unroll
-          for (int rd = 0; rd < DR; ++rd)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) nx[rd][q] = Wc[rd][3];
-          emit_rows(c_last, nx);
-        }
-        left -= e_hi - e_lo;
-        ++b;
-        e_lo = 0;
-        piece_open = false;
-        continue;
-      }
-    }
-    int nchunk = chunk + p.step_chunks, nb = b + p.step_utts;
-    if (nchunk >= p.chunks_per_utt) {
-      nchunk -= p.chunks_per_utt;
-      ++nb;
-    }
-    const int pb = nb < p.num_utts ? nb : b;  // record to fetch (any valid one past the end)
-    const int tb = chunk * G::GROUPS;  // first frame of the chunk (frames * S fits an int)
-    if constexpr (DYN) {
-      if (p.dyn) fetch_ticket();
-    }
-    if (!STRETCH && tb >= nfr) {  // uniform: utterance shorter than the longest
-      if (DYN && p.dyn) {
-        next_item_dyn(nfr, n, sig_off, out_row);
-        continue;
-      }
-      b = nb;
-      chunk = nchunk;
-      nfr = (int)load_const(p.nframes + pb);
-      n = (int)load_const(p.lengths + pb);
-      sig_off = load_const(p.offsets + pb);
-      out_row = load_const(p.row_off + pb);
-      continue;
-    }
-    PDS_STAMP(7, 0);  // item bookkeeping (and whatever the previous item left undrained)
-    if constexpr (PDS_STAMPS != 0) ++st_acc[6];
-    PDS_PHASE(0);
-    // PF: the next item's record now (it is needed in the middle of this item, for the prefetch)
-    [[maybe_unused]] int nfr_nx = 0, n_nx = 0;
-    [[maybe_unused]] int64_t sig_off_nx = 0, out_row_nx = 0;
-    // (issued behind the window multiplies: scalar loads return out of order, so the next wait for an LDS read
-    // is a wait for them too -- from there the in-lane transform covers them)
-    [[maybe_unused]] auto fetch_next_record = [&]() {
-      __builtin_amdgcn_sched_barrier(0);
-      nfr_nx = (int)load_const(p.nframes + pb);
-      n_nx = (int)load_const(p.lengths + pb);
-      sig_off_nx = load_const(p.offsets + pb);
-      out_row_nx = load_const(p.row_off + pb);
-    };
-    // the prefetch: 25 loads whatever the next item is -- an item that is not regular (or none) re-reads the
-    // lane's window slice instead, so that the loads sit in straight-line code the scheduler may spread over
-    // the arithmetic that follows (a branch around them would pin them in a block of their own)
-    [[maybe_unused]] auto issue_prefetch = [&]() {
-      const int tb2 = nchunk * G::GROUPS, s02 = tb2 * S - p.pad_left;
-      pf_ready = nb < p.num_utts && tb2 + G::GROUPS <= nfr_nx && s02 >= 0 && s02 + (G::GROUPS - 1) * S + LOADSPAN <= n_nx;
-      const float *base = pf_ready ? static_cast<const float *>(p.sig) + (sig_off_nx + s02) : p.win_lane;
-      const float *xp2 = base + (pf_ready ? pf_lane : r);
-#pragma unroll
-      for (int n1 = 0; n1 < NROWS; ++n1) {
-        pfv[n1] = xp2[n1 * N2];
-#if PDS_PF_ILV > 0
-        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);          // one load
-        __builtin_amdgcn_sched_group_barrier(0x002, PDS_PF_ILV, 0);  // then vector instructions of what follows
-#endif
-      }
-    };
-    const TIN *x = static_cast<const TIN *>(p.sig) + sig_off;
-    const int start0 = tb * S - p.pad_left;
-    bool valid = true;
-    float energy = 0.0f;
-    // W_(2 N2)^r, twiddle of lane r in the distributed untangling of the even/odd-sum column:
-    // re-read from LDS every iteration rather than held in two registers per lane -- the kernel
-    // sits exactly at the 128-VGPR occupancy step
-    const float2 sw = sw_lds[r];
-    [[maybe_unused]] float even_sum, odd_sum, Ar[COLS], Ai[COLS];  // (in-lane front end)
-    if constexpr (MF > 0) {
-      // ---- matrix-pipe front end (mfma_front.h).  Here a lane is (k-slot q = g, residue r) of
-      // EVERY frame of the item; frame starts are scalars.
-      int fstart[4];
-#pragma unroll
-      for (int fg = 0; fg < 4; ++fg) fstart[fg] = start0 + fg * S;
-      int wmode = 0;
-      if (!(tb + 4 <= nfr && start0 >= (PRE ? 1 : 0) && start0 + 3 * S + NROWS * 16 <= n)) {
-        // frames past the utterance's last one recompute the last frame (their rows are never
-        // stored); frames touching a signal end are gathered with reflected indices
-        valid = tb + g < nfr;
-#pragma unroll
-        for (int fg = 0; fg < 4; ++fg) {
-          const int st = (tb + fg < nfr ? tb + fg : nfr - 1) * S - p.pad_left;
-          fstart[fg] = st;
-          int mode = (st < (PRE ? 1 : 0) || st + NROWS * 16 > n) ? 1 : 0;
-          if (st < -n || st + L > 2 * n) mode = 2;
-          wmode = mode > wmode ? mode : wmode;
-        }
-      }
-      float xs[4][MSLOTS];
-      if (wmode == 0) {
-#pragma unroll
-        for (int fg = 0; fg < 4; ++fg) {
-          // scalar frame base + the lane's 32-bit byte offset: no 64-bit vector arithmetic
-          const char *xg = reinterpret_cast<const char *>(reinterpret_cast<const float *>(x) + fstart[fg]);
-#pragma unroll
-          for (int sl = 0; sl < MSLOTS; ++sl) {
-            float v = (PDS_ABLATE & 1) ? (float)(lane + sl) : *reinterpret_cast<const float *>(xg + moff[sl]);
-            if constexpr (PRE) v = preemph_sample(v, *reinterpret_cast<const float *>(xg + moff[sl] - 4), p.preemph);
-            xs[fg][sl] = v;
-          }
-        }
-      } else {
-        float *tmp = wbase;
-        const int *offs = reinterpret_cast<const int *>(p.mf_tab) + MSLOTS * 64 + lane;
-#pragma unroll 1
-        for (int fg = 0; fg < 4; ++fg) {
-          const int st = fstart[fg];
-#pragma unroll 1
-          for (int sl = 0; sl < MSLOTS; ++sl) {
-            int i = st + offs[sl * 64];
-            if (wmode == 1) {
-              i = i < 0 ? -1 - i : (i >= n ? 2 * n - 1 - i : i);
-            } else {
-              i = (int)reflect_index((int64_t)i, (int64_t)n);
-            }
-            float v = (float)x[i];
-            if (PRE && i > 0) v = preemph_sample(v, (float)x[i - 1], p.preemph);
-            tmp[(fg * MSLOTS + sl) * 64 + lane] = v;
-          }
-        }
-        wave_sync();
-#pragma unroll
-        for (int fg = 0; fg < 4; ++fg)
-#pragma unroll
-          for (int sl = 0; sl < MSLOTS; ++sl) xs[fg][sl] = tmp[(fg * MSLOTS + sl) * 64 + lane];
-        wave_sync();
-      }
-      if (p.include_energy) {
-        // compute.py:392-393 on the un-windowed samples: a slot counts where it is a sample of the
-        // frame of its own (mask table); lane sums, then the 16 lanes of a row, then the four rows
-        const float *em = p.mf_tab + 2 * MSLOTS * 64 + lane;
-        float eg[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-#pragma unroll
-        for (int sl = 0; sl < MSLOTS; ++sl) {
-          const float m = em[sl * 64];
-#pragma unroll
-          for (int fg = 0; fg < 4; ++fg) {
-            const float xm = mul_legacy(xs[fg][sl], m);
-            eg[fg] = fmaf(xm, xm, eg[fg]);
-          }
-        }
-#pragma unroll
-        for (int fg = 0; fg < 4; ++fg) {
-          float e = eg[fg];
-          e = dpp_add<0xB1>(e);   // quad_perm [1,0,3,2]
-          e = dpp_add<0x4E>(e);   // quad_perm [2,3,0,1]
-          e = dpp_add<0x141>(e);  // row_half_mirror
-          e = dpp_add<0x140>(e);  // row_mirror: every lane of a row holds the row's sum
-          const int ei = __float_as_int(e);
-          const float tot = (__int_as_float(__builtin_amdgcn_readlane(ei, 0)) +
-                             __int_as_float(__builtin_amdgcn_readlane(ei, 16))) +
-                            (__int_as_float(__builtin_amdgcn_readlane(ei, 32)) +
-                             __int_as_float(__builtin_amdgcn_readlane(ei, 48)));
-          if (g == fg) energy = tot;
-        }
-      }
-      PDS_STAMP(0, 0);  // frame loads issued
-      PDS_STAMP(1, 1);  // ... and arrived
-      PDS_PHASE(4);
-      float sv[4][MF], dv[4][MF], cv[4], uv[4];
-#pragma unroll
-      for (int fg = 0; fg < 4; ++fg) {
-        // (plain multiplies: a slot without a sample of its own re-reads a sample of the SAME frame
-        // with weight zero, so nothing from outside the frame can reach it)
-        cv[fg] = xs[fg][2 * MF] * mwin[2 * MF];
-        float u = cv[fg];
-#pragma unroll
-        for (int t = 0; t < MF; ++t) {
-          const float a = xs[fg][2 * t] * mwin[2 * t];
-          sv[fg][t] = fmaf(xs[fg][2 * t + 1], mwin[2 * t + 1], a);
-          dv[fg][t] = fmaf(-xs[fg][2 * t + 1], mwin[2 * t + 1], a);
-          u += sv[fg][t];
-        }
-        uv[fg] = u;
-      }
-      f32x4 accR[4], accI[4];
-#pragma unroll
-      for (int fg = 0; fg < 4; ++fg) {
-        accR[fg] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-        accI[fg] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-      }
-      if constexpr (!(PDS_ABLATE & 2)) {
-#pragma unroll
-        for (int t = 0; t < MF; ++t)
-#pragma unroll
-          for (int fg = 0; fg < 4; ++fg) {
-            accR[fg] = __builtin_amdgcn_mfma_f32_16x16x4f32(mare[t], sv[fg][t], accR[fg], 0, 0, 0);
-            accI[fg] = __builtin_amdgcn_mfma_f32_16x16x4f32(maim[t], dv[fg][t], accI[fg], 0, 0, 0);
-          }
-#pragma unroll
-        for (int fg = 0; fg < 4; ++fg) {
-          accR[fg] = __builtin_amdgcn_mfma_f32_16x16x4f32(mare[MF], cv[fg], accR[fg], 0, 0, 0);
-          accI[fg] = __builtin_amdgcn_mfma_f32_16x16x4f32(maim[MF], uv[fg], accI[fg], 0, 0, 0);
-        }
-      } else {
-#pragma unroll
-        for (int fg = 0; fg < 4; ++fg) {
-          accR[fg] = f32x4{sv[fg][0], sv[fg][1], sv[fg][2], cv[fg]};
-          accI[fg] = f32x4{dv[fg][0], dv[fg][1], dv[fg][2], uv[fg]};
-        }
-      }
-      // the lane's rows 4 q + v are columns k1 = 4 q + v + 1 of every frame; row 15 (q = 3, v = 3)
-      // holds the even / odd row sums, which go to row 0 of the frame's exchange block
-      PDS_PHASE(1);
-      float2 *mine = reinterpret_cast<float2 *>(wbase) + (4 * g + 1) * RS + r;
-      float *row0 = wbase + r;
-#pragma unroll
-      for (int fg = 0; fg < 4; ++fg) {
-#pragma unroll
-        for (int v = 0; v < 4; ++v) {
-          float2 val;
-          val.x = accR[fg][v] * mtwr[v] - accI[fg][v] * mtwi[v];
-          val.y = accR[fg][v] * mtwi[v] + accI[fg][v] * mtwr[v];
-          if (v < 3 || g != 3) {
-            mine[fg * COLS * RS + v * RS] = val;
-          } else {
-            row0[fg * COLS * RS * 2] = accR[fg][3];
-            row0[fg * COLS * RS * 2 + 16] = accI[fg][3];
-          }
-        }
-      }
-    } else {
-      // Common case, decided on scalars: all GROUPS frames exist and every row they read lies
-      // inside the signal.  Otherwise per-lane bookkeeping: lanes of a frame past the end
-      // recompute the last frame (their rows are never stored); frames touching a signal end are
-      // gathered with reflected indices (1: one bounce suffices, 2: general reflection).
-      int start = start0 + __mul24(g, S);  // (24-bit multiplies issue at full rate, 32-bit ones at a quarter)
-      int wmode = 0;
-      if (!(PF && pf_ready) && !(tb + G::GROUPS <= nfr && start0 >= (PRE ? 1 : 0) &&
-            start0 + (G::GROUPS - 1) * S + LOADSPAN <= n)) {
-        valid = tb + g < nfr;
-        start = (valid ? tb + g : nfr - 1) * S - p.pad_left;
-        int mode = 0;
-        // (with fused pre-emphasis the direct loads also read x[start - 1])
-        if (start < (PRE ? 1 : 0) || start + LOADSPAN > n) mode = 1;
-        if (start < -n || start + L > 2 * n) mode = 2;
-        wmode = __builtin_amdgcn_readfirstlane(__any(mode == 2) ? 2 : (__any(mode == 1) ? 1 : 0));
-      }
-
-      float a[N1];
-      if (PF && pf_ready) {
-        // (a regular item by construction: wmode = 0, valid)
-#pragma unroll
-        for (int n1 = 0; n1 < NROWS; ++n1) a[n1] = pfv[n1];
-      } else if (wmode == 0) {
-        // Lanes past the frame's end in the last row read samples of the next frame; the
-        // window (exactly 0 there, applied with the 0 * x = 0 multiply) removes them.
-        const TIN *xp = x + (start + r);
-        if constexpr (PAIR) {
-          typedef double D2 __attribute__((ext_vector_type(2), aligned(8)));
-          const TIN *xq = x + (start + 2 * r);  // the lane's pair inside every block of two rows
-          // (all loads first: the lane exchanges below are convergent operations, which the compiler
-          // does not move loads across -- interleaved in the source, every load waited for the one before)
-          constexpr int NP = (NROWS + 1) / 2;
-          D2 w2[NP];
-          [[maybe_unused]] double wprev[PRE ? NP : 1];
-#pragma unroll
-          for (int j = 0; j < NP; ++j) {
-            w2[j] = *reinterpret_cast<const D2 *>(xq + 32 * j);
-            if constexpr (PRE) wprev[j] = xq[32 * j - 1];
-          }
-#pragma unroll
-          for (int j = 0; j < NP; ++j) {
-            double u = w2[j].x, v = w2[j].y;
-            if constexpr (PRE) {
-              // float64 pre-emphasis before the rounding (pre.py:140-149): v's predecessor is u
-              v = preemph_sample(w2[j].y, w2[j].x, (TIN)p.preemph_d);
-              u = preemph_sample(w2[j].x, wprev[j], (TIN)p.preemph_d);
-            }
-            const float fu = (float)u, fv = (float)v;
-            // lanes 8..15 take residue 2s + 1 of the even row from lane s; lanes 0..7 take residue 2s of
-            // the odd row from lane s + 8 (row_ror:8 = lane ^ 8, bank masks pick the receiving half)
-            a[2 * j] = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(fu), __float_as_int(fv), 0x128, 0xf, 0xc, false));
-            if (2 * j + 1 < NROWS)
-              a[2 * j + 1] = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(fv), __float_as_int(fu), 0x128, 0xf, 0x3, false));
-          }
-        } else if constexpr (!std::is_same<TIN, float>::value) {
-          // float64 samples: 8-byte loads, pre-emphasis in float64 (bit-identical to the reference's
-          // own pass, pre.py:140-149), one rounding to float32
-#pragma unroll
-          for (int n1 = 0; n1 < NROWS; ++n1) {
-            TIN v = xp[n1 * N2];
-            if constexpr (PRE) v = preemph_sample(v, xp[n1 * N2 - 1], (TIN)p.preemph_d);
-            a[n1] = (float)v;
-          }
-        } else {
-#pragma unroll
-        for (int n1 = 0; n1 < NROWS; ++n1) a[n1] = (PDS_ABLATE & 1) ? (float)(lane + n1) : (float)xp[n1 * N2];
-        }
-        if constexpr (PRE && std::is_same<TIN, float>::value) {
-          // predecessor of lane r's sample: lane r - 1 of the same row, or (r = 0) the last lane
-          // of the previous row.  With 16 lanes per frame a lane group is one DPP row and
-          // row_ror:1 delivers both; other group sizes load the predecessor.
-          if constexpr (N2 == 16) {
-            float carry = 0.0f;
-            if (r == 0) carry = (float)xp[-1];
-#pragma unroll
-            for (int n1 = 0; n1 < NROWS; ++n1) {
-              const float rot = __int_as_float(__builtin_amdgcn_update_dpp(
-                  0, __float_as_int(a[n1]), 0x121 /* row_ror:1 */, 0xf, 0xf, false));
-              const float prev = r == 0 ? carry : rot;
-              carry = rot;
-              a[n1] = preemph_sample(a[n1], prev, p.preemph);
-            }
-          } else {
-#pragma unroll
-            for (int n1 = 0; n1 < NROWS; ++n1) a[n1] = preemph_sample(a[n1], (float)xp[n1 * N2 - 1], p.preemph);
-          }
-        }
-      } else {
-        float *tmp = wbase;
-#pragma unroll 1
-        for (int n1 = 0; n1 < NROWS; ++n1) {
-          const int idx = n1 * N2 + rho;
-          float v = 0.0f;
-          if (idx < L) {
-            int i = start + idx;
-            if (wmode == 1) {
-              i = i < 0 ? -1 - i : (i >= n ? 2 * n - 1 - i : i);
-            } else {
-              i = (int)reflect_index((int64_t)i, (int64_t)n);
-            }
-            if constexpr (std::is_same<TIN, float>::value) {
-              v = (float)x[i];
-              if (PRE && i > 0) v = preemph_sample(v, (float)x[i - 1], p.preemph);
-            } else {
-              TIN w = x[i];
-              if (PRE && i > 0) w = preemph_sample(w, x[i - 1], (TIN)p.preemph_d);
-              v = (float)w;
-            }
-          }
-          tmp[n1 * 64 + lane] = v;
-        }
-        wave_sync();
-#pragma unroll
-        for (int n1 = 0; n1 < NROWS; ++n1) a[n1] = tmp[n1 * 64 + lane];
-        wave_sync();
-      }
-      if (p.include_energy) {
-        // compute.py:392-393, on the un-windowed samples of the frame proper
-        // Rows below N1/2 lie inside the frame (this kernel requires L > N/2); the others are
-        // masked against L.  The limit goes through an opaque asm so that the compares are made
-        // here, per item: hoisted out of the loop they would sit in one scalar register pair per
-        // row for the whole kernel.
-        int lim = L - rho;
-        asm volatile("" : "+v"(lim));
-#pragma unroll
-        for (int n1 = 0; n1 < NROWS; ++n1) {
-          const float v = (n1 < N1 / 2 || n1 * N2 < lim) ? a[n1] : 0.0f;
-          energy = fmaf(v, v, energy);
-        }
-      }
-      PDS_STAMP(0, 0);  // frame loads issued
-      PDS_STAMP(1, 1);  // ... and arrived
-      PDS_PHASE(4);
-      if constexpr (WINLDS) {
-#pragma unroll
-        for (int n1 = 0; n1 < NROWS; ++n1) a[n1] = mul_legacy(a[n1], wl[n1]);
-      } else {
-#pragma unroll
-        for (int n1 = 0; n1 < NROWS; ++n1) a[n1] = mul_legacy(a[n1], win[n1]);
-      }
-      if constexpr (PF) fetch_next_record();
-#pragma unroll
-      for (int n1 = NROWS; n1 < N1; ++n1) a[n1] = 0.0f;
-
-      if constexpr (PDS_ABLATE & 2) {
-        even_sum = a[0];
-        odd_sum = a[1];
-#pragma unroll
-        for (int k = 0; k < COLS; ++k) {
-          Ar[k] = a[2 * k];
-          Ai[k] = a[2 * k + 1];
-        }
-      } else if constexpr (inl::is_pow2(N1)) {
-        inl::rdft_scaled<N1>(a, even_sum, odd_sum, Ar, Ai);
-      } else {
-        inl::rdft_direct<N1>(a, even_sum, odd_sum, Ar, Ai);
-      }
-
-      // transpose through LDS: row k1 of this frame's block holds column k1 for all n2; row 0
-      // holds c[j] = sum_q xw[j + 2 N2 q] (j < 2 N2), the input of the multiples of N1/2.  (Odd
-      // N1: c[j] = sum_q xw[j + N2 q] for j < N2 and zeros above, whose 2 N2-point transform has
-      // the multiples of N1 at its even outputs; the odd ones are not bins and are dropped.)
-      PDS_PHASE(1);
-      {
-        float *row0 = reinterpret_cast<float *>(exch);
-        row0[rho] = even_sum;
-        row0[N2 + rho] = odd_sum;
-      }
-      [[maybe_unused]] float ctr[TWCHAIN ? COLS : 1], cti[TWCHAIN ? COLS : 1];
-      if constexpr (TWCHAIN) inl::twiddle_chain15(sd[0], sd[1], sd[2], sd[3], sd[4], sd[5], ctr, cti);
-#pragma unroll
-      for (int k1 = 1; k1 <= NREG; ++k1) {
-        const float wr_ = TWCHAIN ? ctr[TWCHAIN ? k1 : 0] : twr[TWCHAIN ? 0 : k1];
-        const float wi_ = TWCHAIN ? cti[TWCHAIN ? k1 : 0] : twi[TWCHAIN ? 0 : k1];
-        float2 v;
-        v.x = Ar[k1] * wr_ - Ai[k1] * wi_;
-        v.y = Ar[k1] * wi_ + Ai[k1] * wr_;
-        if constexpr (PDS_ABLATE & 4) {
-          Ar[k1] = v.x;
-          Ai[k1] = v.y;
-        } else {
-          exch[k1 * RS + rho] = v;
-        }
-      }
-    }
-    PDS_STAMP(2, 0);  // window, N1-point transform, twiddles, exchange stores issued
-    if constexpr (PDS_STAGGER) __builtin_amdgcn_s_barrier();
-    wave_sync();
-
-    float pw[G::CPL][N2 + 1];
-    float sp0 = 0.0f, sp1 = 0.0f;  // the two special bins of lane r <= N2/2
-    // PSPLIT (N = 4096 = 64 x 64, one frame per wave): the 32 columns would occupy half the wave and each
-    // lane a 64-point transform (256 registers of data).  Instead a column is shared by the lane PAIR
-    // (c, c + 32): the lower lane transforms the even-numbered column elements, the upper lane the odd ones
-    // (32 points each), `v_permlane32_swap` hands each lane one half of the other's outputs, and the lane
-    // finishes the radix-2 step for 16 values of k: Y[k'] = A + W_64^k' B and Y[k' + 32] = A - W_64^k' B,
-    // k' = k + 16 h.  Every lane works in this phase, on half the data.
-    // (The same for 32 lanes per frame and 16 columns -- N = 1024 as 32 x 32, two frames per wave, lane pairs
-    // (c, c + 16) through v_permlane16_swap: the 64 x 16 form of that size holds a 64-point in-lane real
-    // transform, 256 registers and 18 KB of LDS per wave; this one 128 and 8.7.)
-    constexpr bool PSPLIT = PDS_PAIR_SPLIT && N2 == 2 * COLS && (N2 == 64 || N2 == 32);
-    constexpr int PH = N2 / 2, PQ = N2 / 4;  // points of a lane's transform, values of k it finishes
-    [[maybe_unused]] const int ph = r / (N2 / 2), pc = r % (N2 / 2);
-    if constexpr (PSPLIT) {
-      static_assert(!PSPLIT || (G::CPL == 1 && COLS == PH), "pair split: the columns fill half the frame's lanes");
-      const float4 *row = reinterpret_cast<const float4 *>(exch + pc * RS);
-      float zr[PH], zi[PH], Hr[PH], Hi[PH];
-#pragma unroll
-      for (int j = 0; j < PH; ++j) {
-        const float4 v = row[j];  // elements 2 j and 2 j + 1 of the column
-        zr[j] = ph ? v.z : v.x;
-        zi[j] = ph ? v.w : v.y;
-      }
-      PDS_PHASE(5);
-      inl::CFFT<PH, 1>::run(zr, zi, Hr, Hi);  // A (lower lane) or B (upper lane)
-      PDS_PHASE(2);
-      inl::static_for<0, PQ>([&](auto k_) {
-        constexpr int k = decltype(k_)::value;
-        // (first' = first.lo | second.lo, second' = first.hi | second.hi, lo / hi = the halves of a frame's lane
-        // group): lower lane A[k], B[k]; upper lane A[k + PQ], B[k + PQ]
-        float ar, br, ai, bi;
-        if constexpr (N2 == 64) {
-          const auto sr_ = __builtin_amdgcn_permlane32_swap(__float_as_uint(Hr[k]), __float_as_uint(Hr[k + PQ]), false, false);
-          const auto si_ = __builtin_amdgcn_permlane32_swap(__float_as_uint(Hi[k]), __float_as_uint(Hi[k + PQ]), false, false);
-          ar = __uint_as_float(sr_[0]), br = __uint_as_float(sr_[1]);
-          ai = __uint_as_float(si_[0]), bi = __uint_as_float(si_[1]);
-        } else {
-          const auto sr_ = __builtin_amdgcn_permlane16_swap(__float_as_uint(Hr[k]), __float_as_uint(Hr[k + PQ]), false, false);
-          const auto si_ = __builtin_amdgcn_permlane16_swap(__float_as_uint(Hi[k]), __float_as_uint(Hi[k + PQ]), false, false);
-          ar = __uint_as_float(sr_[0]), br = __uint_as_float(sr_[1]);
-          ai = __uint_as_float(si_[0]), bi = __uint_as_float(si_[1]);
-        }
-        // t = W_N2^(k + PQ h) B = (-i)^h (W_N2^k B)
-        float ur, ui;
-        inl::mul_tw<N2, k>(br, bi, ur, ui);
-        const float tr = ph ? ui : ur, ti = ph ? -ur : ui;
-        const float yar = ar + tr, yai = ai + ti, ybr = ar - tr, ybi = ai - ti;
-        pw[0][k] = yar * yar + yai * yai;            // k2 = k + PQ h
-        pw[0][PQ + k] = ybr * ybr + ybi * ybi;       // k2 = k + PQ h + PH
-        if (pc == 0) {
-          // the packed real column (the pair's two lanes): its outputs go to row 0 of the exchange block for
-          // the lanes that untangle one bin pair each (both lanes are past reading the row)
-          exch[k + PQ * ph] = make_float2(yar, yai);
-          exch[k + PQ * ph + PH] = make_float2(ybr, ybi);
-        }
-      });
-#pragma unroll
-      for (int k2 = PH; k2 <= N2; ++k2) pw[0][k2] = 0.0f;
-      wave_sync();
-      {
-        const float2 ya = exch[r], yb = exch[(N2 - r) & (N2 - 1)];
-        const float ar = ya.x, ai = ya.y, br = yb.x, bi = yb.y;
-        const float sr = ar + br, si = ai - bi;
-        const float dr = ar - br, di = ai + bi;
-        const float tr = sw.x * di + sw.y * dr;
-        const float ti = sw.y * di - sw.x * dr;
-        const float xr = sr + tr, xi = si + ti;  // 2 X[m]
-        const float yr = sr - tr, yi = ti - si;  // 2 X[N2 - m]
-        sp0 = 0.25f * (xr * xr + xi * xi);
-        sp1 = 0.25f * (yr * yr + yi * yi);
-      }
-    } else
-#pragma unroll
-    for (int q = 0; q < G::CPL; ++q) {
-      const int kk = q * N2 + r;
-      const float4 *row = reinterpret_cast<const float4 *>(exch + kk * RS);
-      float zr[N2], zi[N2], Yr[N2], Yi[N2];
-#pragma unroll
-      for (int j = 0; j < N2 / 2; ++j) {
-        float4 v;
-        if constexpr (PDS_ABLATE & 4) {
-          v = make_float4(Ar[(2 * j) % COLS], Ai[(2 * j) % COLS], Ar[(2 * j + 1) % COLS], Ai[(2 * j + 1) % COLS]);
-        } else {
-          v = row[j];
-        }
-        zr[2 * j] = v.x;
-        zi[2 * j] = v.y;
-        zr[2 * j + 1] = v.z;
-        zi[2 * j + 1] = v.w;
-      }
-      // PF: the next item's loads behind this item's column reads (which the transform waits for), spread over
-      // the transform's arithmetic
-      // (the transform's priority is set in front of them: s_setprio is a scheduling boundary)
-      if constexpr (PF && PDS_PF_PLACE == 0) {
-        PDS_PHASE(5);
-#if PDS_PF_ILV > 0
-        __builtin_amdgcn_sched_group_barrier(0x100, N2 / 2, 0);  // the column reads first
-#endif
-        if (q == 0) issue_prefetch();
-      }
-      if constexpr (PDS_ABLATE & 8) {
-#pragma unroll
-        for (int k2 = 0; k2 < N2; ++k2) {
-          Yr[k2] = zr[k2];
-          Yi[k2] = zi[k2];
-        }
-      } else {
-        if constexpr (!(PF && PDS_PF_PLACE == 0)) PDS_PHASE(5);
-        inl::CFFT<N2, 1>::run(zr, zi, Yr, Yi);
-        if (q + 1 < G::CPL) {
-          PDS_PHASE(1);
-        } else {
-          PDS_PHASE(2);
-        }
-      }
-      // regular columns; lane 0 (q = 0) holds Y = FFT(c[2m] + i c[2m+1]) of the even/odd sums
-#pragma unroll
-      for (int k2 = 0; k2 < N2; ++k2) pw[q][k2] = Yr[k2] * Yr[k2] + Yi[k2] * Yi[k2];
-      pw[q][N2] = 0.0f;
-      if constexpr (!G::DIST) {
-        // 8 lanes per frame: lane 0 untangles its short packed-sum transform itself (spreading
-        // it would cost registers these geometries do not have)
-        if (q == 0 && r == 0)
-          inl::rdft_finish_power<2 * N2>(Yr, Yi, [&](auto mm, float re, float im) {
-            pw[q][decltype(mm)::value] = re * re + im * im;
-          });
-      } else if (q == 0) {
-        // The bins m * N1/2 need Y[m] and Y[N2 - m] of that lane: lanes 0..N2/2 untangle one bin
-        // pair each -- a few moves + 20 flops for every lane instead of a block of ~10 N2
-        // instructions that only lane 0 needs.
-        float ar, ai, br, bi;
-        if constexpr (N2 == 16) {
-          // a lane group is one DPP row, so "row_shr:m, keep old where the source lane is outside
-          // the row", applied for m = 1, 2, ... in order, leaves lane m with lane 0's register m
-          ar = Yr[0], ai = Yi[0], br = Yr[0], bi = Yi[0];
-          inl::static_for<1, N2 / 2 + 1>([&](auto mm) {
-            constexpr int m = decltype(mm)::value;
-            ar = dpp_row_shr_keep<m>(ar, Yr[m]);
-            ai = dpp_row_shr_keep<m>(ai, Yi[m]);
-            br = dpp_row_shr_keep<m>(br, Yr[N2 - m]);
-            bi = dpp_row_shr_keep<m>(bi, Yi[N2 - m]);
-          });
-        } else {
-          // other group sizes: lane 0 hands its column over through row 0 of the frame's exchange
-          // block (its only reader, lane 0 itself, is past it)
-          if (r == 0) {
-#pragma unroll
-            for (int k2 = 0; k2 < N2; ++k2) exch[k2] = make_float2(Yr[k2], Yi[k2]);
-          }
-          wave_sync();
-          const float2 ya = exch[r], yb = exch[(N2 - r) & (N2 - 1)];
-          ar = ya.x, ai = ya.y, br = yb.x, bi = yb.y;
-        }
-        const float sr = ar + br, si = ai - bi;
-        const float dr = ar - br, di = ai + bi;
-        const float tr = sw.x * di + sw.y * dr;
-        const float ti = sw.y * di - sw.x * dr;
-        const float xr = sr + tr, xi = si + ti;  // 2 X[m]
-        const float yr = sr - tr, yi = ti - si;  // 2 X[N2 - m]
-        // (TWCHAIN: the window carries the factor 1/2 already)
-        sp0 = (TWCHAIN ? 1.0f : 0.25f) * (xr * xr + xi * xi);
-        sp1 = (TWCHAIN ? 1.0f : 0.25f) * (yr * yr + yi * yi);
-      }
-    }
-    if (!use_power) {
-#pragma unroll
-      for (int q = 0; q < G::CPL; ++q)
-#pragma unroll
-        for (int k2 = 0; k2 <= N2; ++k2) pw[q][k2] = __builtin_amdgcn_sqrtf(pw[q][k2]);
-      sp0 = __builtin_amdgcn_sqrtf(sp0);
-      sp1 = __builtin_amdgcn_sqrtf(sp1);
-    }
-    // row lengths and table offsets of the first USLOTS slots (tables padded to USLOTS entries):
-    // fetched here so that the P stores below cover the latency.  (Scalar loads return out of
-    // order, so a wait for one is a wait for all: they are issued in two batches per item, this
-    // one and the next item's record at the start of the filter phase.)
-    Int4 lens4 = {0, 0, 0, 0}, woff4 = {0, 0, 0, 0};
-    if constexpr (!RSG && !SEG) {
-      lens4 = load_const(reinterpret_cast<const Int4 *>(p.ell_len));
-      woff4 = load_const(reinterpret_cast<const Int4 *>(p.ell_woff));
-    }
-    const int slot_len[USLOTS] = {lens4.x, lens4.y, lens4.z, lens4.w};
-    const int slot_woff[USLOTS] = {woff4.x, woff4.y, woff4.z, woff4.w};
-    static_assert(USLOTS == 4, "slot tables are fetched as one int4 each");
-    // every lane is done with the exchange area (same wave, in order): reuse it as P
-    PDS_STAMP(3, 0);  // exchange reads, N2-point transforms, power spectrum
-    wave_sync();
-    // Stores below avoid lane predicates (each costs exec-mask bookkeeping on the scalar unit):
-    // lanes without a value of their own write to a padding slot that is zeroed afterwards.
-    // P[frame][bin] (row stride PSTR), or bin-major P[bin][frame] for the row-segment walk
-    float *const Pw = RSG ? wbase + g : Pg;           // the lane's frame
-    constexpr int PB = RSG ? 4 : 1;                   // floats per bin step
-    constexpr int PDUMP = RSG ? NBP : PSTR - 1;       // bin index of the padding slot
-    if constexpr (PSPLIT) {
-      // the lane's bins: pc + N1 k2 for k2 = k + PQ h, and the mirror images N - pc - N1 (k2 + PH)
-      const int lo_bin = pc + N1 * PQ * ph, hi_bin = N / 2 - pc - N1 * PQ * ph;
-#pragma unroll
-      for (int k = 0; k < PQ; ++k) {
-        Pw[(lo_bin + N1 * k) * PB] = pw[0][k];
-        Pw[(hi_bin - N1 * k) * PB] = pw[0][PQ + k];
-      }
-    } else
-#pragma unroll
-    for (int q = 0; q < G::CPL; ++q) {
-      const int kk = q * N2 + r;
-      if (!G::DIST && q == 0 && r == 0) {
-        // output m of the 2 N2-point transform is bin m N1 / 2 (odd N1: even m only)
-#pragma unroll
-        for (int m = 0; m <= N2; m += (N1 % 2 ? 2 : 1)) Pw[(m * N1 / 2) * PB] = pw[q][m];
-      } else {
-        // (DIST: lane 0 of q = 0 writes its meaningless column to multiples of N1, all of which
-        // the special bins written next overwrite).  Lanes beyond the last column (only when the
-        // columns do not fill the lanes) send theirs to the padding slot.
-        const bool live = G::FULL || kk < COLS;
-#pragma unroll
-        for (int k2 = 0; k2 < N2; ++k2) {
-          // bin kk + N1*k2, or its mirror image when beyond N/2
-          const int bin = (k2 < N2 / 2) ? kk + N1 * k2 : N - kk - N1 * k2;
-          Pw[(live ? bin : PDUMP) * PB] = pw[q][k2];
-        }
-      }
-    }
-    if constexpr (G::DIST) {
-      // output m of the 2 N2-point transform is bin m N1 / 2 (odd N1: even m only)
-      const bool has = r <= N2 / 2 && (N1 % 2 == 0 || r % 2 == 0);
-      Pw[(has ? r * N1 / 2 : PDUMP) * PB] = sp0;
-      Pw[(has ? (N2 - r) * N1 / 2 : PDUMP) * PB] = sp1;
-    }
-    // slots past the last bin are read (with weight 0) by the filter walk: keep them finite
-    if constexpr (RSG) {
-      constexpr int PADF = (NBP - NB) * 4;  // 4 .. 12 floats behind the last bin
-      wbase[NB * 4 + (lane < PADF ? lane : PADF - 1)] = 0.0f;
-    } else {
-#pragma unroll
-      for (int j0 = 0; j0 < PSTR - NB; j0 += N2) {
-        const int j = j0 + r;
-        Pg[NB + (j < PSTR - NB ? j : PSTR - NB - 1)] = 0.0f;
-      }
-    }
-    // ---- filter bank: lane (g, r) integrates one filter per slot
-    // scalar row base + a 32-bit lane offset: no 64-bit vector arithmetic per store
-    TOUT *obase = static_cast<TOUT *>(p.out) + (out_row + tb) * p.out_stride;
-    const unsigned lane_off = (unsigned)(g * (int)p.out_stride + col0);
-    if (p.include_energy) {
-      // sum over the frame's lanes with DPP butterflies (lanes 1^, 2^, 7-, 15- within the row);
-      // every lane ends up with the total, lane 0 of the frame stores it (compute.py:392-398)
-      // (the matrix-pipe front end has summed it already)
-      if constexpr (MF == 0) {
-        energy = dpp_add<0xB1>(energy);   // quad_perm [1,0,3,2]
-        energy = dpp_add<0x4E>(energy);   // quad_perm [2,3,0,1]
-        energy = dpp_add<0x141>(energy);  // row_half_mirror
-        if constexpr (N2 >= 16) energy = dpp_add<0x140>(energy);  // row_mirror
-        if constexpr (N2 >= 32) energy += __shfl_xor(energy, 16, 64);
-        if constexpr (N2 == 64) energy += __shfl_xor(energy, 32, 64);
-      }
-      float e = energy * p.inv_L;
-      if (!use_power) e = __builtin_amdgcn_sqrtf(e);
-      if (p.use_log) e = fast_log(p.log_floor > e ? p.log_floor : e);
-      if (DLT == 0 && valid && r == 0) obase[lane_off - col0] = (TOUT)e;
-      if constexpr (DLT > 0) e_keep = e;
-    }
-    PDS_STAMP(4, 0);  // P stores, energy
-    PDS_PHASE(3);
-    int metas[USLOTS] = {0};  // first bin of the lane's row | (filter + 1) << 16, per slot
-    if constexpr (!RSG && !SEG) {
-#pragma unroll
-      for (int sl = 0; sl < USLOTS; ++sl) metas[sl] = meta_lds[sl * N2 + r];
-    }
-    wave_sync();
-    [[maybe_unused]] const int frames_here = nfr - tb;  // frames of this chunk that exist (SEG)
-    // this item's record is dead from here on: fetch the next one under the filter phase
-    if constexpr (STRETCH) {
-      // (the piece's record stays)
-    } else if constexpr (PF) {
-      b = nb;
-      chunk = nchunk;
-      nfr = nfr_nx;
-      n = n_nx;
-      sig_off = sig_off_nx;
-      out_row = out_row_nx;
-      if constexpr (PDS_PF_PLACE == 1) issue_prefetch();
-    } else if (DYN && p.dyn) {
-      next_item_dyn(nfr, n, sig_off, out_row);
-    } else {
-      b = nb;
-      chunk = nchunk;
-      nfr = (int)load_const(p.nframes + pb);
-      n = (int)load_const(p.lengths + pb);
-      sig_off = load_const(p.offsets + pb);
-      out_row = load_const(p.row_off + pb);
-    }
-
-    auto run_slot = [&](const int meta, const int len, const int slot_woff_) {
-      const float4 *prow = reinterpret_cast<const float4 *>(Pg + (meta & 0xffff));
-      const int woff = slot_woff_ + __mul24(r, len + 4);  // + 4: conflict-free row skew
-      float acc0 = 0.0f, acc1 = 0.0f, acc2 = 0.0f, acc3 = 0.0f;
-      const float4 *wrow = reinterpret_cast<const float4 *>((ELL_LDS ? ellw_lds : p.ell_w) + woff);
-      // 8 bins per step, two steps per pass of the loop (8 LDS reads in flight per 16
-      // multiply-adds); the trip count is a shift of the row length, which is a multiple of 8
-      auto step = [&]() {
-        // weights and powers of one half, then the other: the first multiply-adds wait for two
-        // reads instead of five (LDS returns in order; +3 % on the dense gammatone bank)
-        const float4 w0 = wrow[0];
-        const float4 p0 = prow[0];
-        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-        const float4 w1 = wrow[1];
-        const float4 p1 = prow[1];
-        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-        acc0 = fmaf(w0.x, p0.x, acc0);
-        acc1 = fmaf(w0.y, p0.y, acc1);
-        acc2 = fmaf(w0.z, p0.z, acc2);
-        acc3 = fmaf(w0.w, p0.w, acc3);
-        acc0 = fmaf(w1.x, p1.x, acc0);
-        acc1 = fmaf(w1.y, p1.y, acc1);
-        acc2 = fmaf(w1.z, p1.z, acc2);
-        acc3 = fmaf(w1.w, p1.w, acc3);
-        wrow += 2;
-        prow += 2;
-      };
-      const unsigned steps = (PDS_ABLATE & 32) ? 1u : (unsigned)len >> 3;
-      if constexpr (N >= PDS_ELL_DEEP_N) {
-        // (256-register geometries: four steps per pass, 16 reads in flight)
-#pragma unroll 1
-        for (unsigned i = steps >> 2; i != 0; --i) {
-          step();
-          step();
-          step();
-          step();
-        }
-        if (steps & 2u) {
-          step();
-          step();
-        }
-      } else {
-#pragma unroll 1
-        for (unsigned i = steps >> 1; i != 0; --i) {
-          step();
-          step();
-        }
-      }
-      if (steps & 1u) step();
-      float acc = (acc0 + acc1) + (acc2 + acc3);
-      // max(val, floor) as Python evaluates it: a NaN stays a NaN (compute.py:459)
-      if (p.use_log) acc = fast_log(p.log_floor > acc ? p.log_floor : acc);
-      if constexpr (PDS_ABLATE & 64) {
-        keep_alive(acc);
-      } else {
-        // filter index f = (meta >> 16) - 1; lanes without a filter in this slot have meta < 2^16
-        const unsigned byte_off = (lane_off + (unsigned)(meta >> 16) - 1u) * (unsigned)sizeof(TOUT);
-        if (valid && meta >= 0x10000)
-          *reinterpret_cast<TOUT *>(reinterpret_cast<char *>(obase) + byte_off) = (TOUT)acc;
-      }
-    };
-    if constexpr (RSG) {
-      // Row-segment walk (rseg_tables.h): lane = one segment of seg_len bins of one filter, for all
-      // four frames; weights [round][seg_len / 4][lane] float4, powers bin-major.
-      const float4 *P4 = reinterpret_cast<const float4 *>(wbase);
-      const int t4n = p.seg_len >> 2;
-      auto round_body = [&](const int rd, float (&logged)[4]) {
-        const int meta = meta_lds[rd * 64 + lane];
-        const float4 *prow = P4 + (meta & 0x3fff);
-        const float4 *wrow = reinterpret_cast<const float4 *>(ellw_lds) + __mul24(rd, t4n) * 64 + lane;
-        float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
-        auto quad = [&](int t4) {
-          const float4 w = wrow[t4 * 64];
-          const float4 x0 = prow[4 * t4], x1 = prow[4 * t4 + 1], x2 = prow[4 * t4 + 2], x3 = prow[4 * t4 + 3];
-          a0 = fmaf(w.x, x0.x, a0);
-          a1 = fmaf(w.x, x0.y, a1);
-          a2 = fmaf(w.x, x0.z, a2);
-          a3 = fmaf(w.x, x0.w, a3);
-          a0 = fmaf(w.y, x1.x, a0);
-          a1 = fmaf(w.y, x1.y, a1);
-          a2 = fmaf(w.y, x1.z, a2);
-          a3 = fmaf(w.y, x1.w, a3);
-          a0 = fmaf(w.z, x2.x, a0);
-          a1 = fmaf(w.z, x2.y, a1);
-          a2 = fmaf(w.z, x2.z, a2);
-          a3 = fmaf(w.z, x2.w, a3);
-          a0 = fmaf(w.w, x3.x, a0);
-          a1 = fmaf(w.w, x3.y, a1);
-          a2 = fmaf(w.w, x3.z, a2);
-          a3 = fmaf(w.w, x3.w, a3);
-        };
-        // the common segment lengths run unrolled, every read of the segment in flight at once
-        if (t4n == 3) {
-          quad(0);
-          quad(1);
-          quad(2);
-        } else if (t4n == 1) {
-          quad(0);
-        } else if (t4n == 2) {
-          quad(0);
-          quad(1);
-        } else {
-#pragma unroll 2
-          for (int t4 = 0; t4 < t4n; ++t4) quad(t4);
-        }
-#if PDS_PF_WINAT == 0
-        read_window();  // (WINLDS: the next item's window slice, behind this round's reads)
-#endif
-        // add up a filter's segments (at most four, on consecutive lanes of one DPP row): lane i takes
-        // lane i + 1's sums where the table says the run continues, then lane i + 2's
-        const float m1 = (meta & (1 << 14)) ? 1.0f : 0.0f, m2 = (meta & (1 << 15)) ? 1.0f : 0.0f;
-        auto shl = [](float v, auto ctrl) {
-          return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), decltype(ctrl)::value, 0xf, 0xf, true));
-        };
-        a0 = fmaf(shl(a0, inl::Int<0x101>{}), m1, a0);
-        a1 = fmaf(shl(a1, inl::Int<0x101>{}), m1, a1);
-        a2 = fmaf(shl(a2, inl::Int<0x101>{}), m1, a2);
-        a3 = fmaf(shl(a3, inl::Int<0x101>{}), m1, a3);
-        a0 = fmaf(shl(a0, inl::Int<0x102>{}), m2, a0);
-        a1 = fmaf(shl(a1, inl::Int<0x102>{}), m2, a1);
-        a2 = fmaf(shl(a2, inl::Int<0x102>{}), m2, a2);
-        a3 = fmaf(shl(a3, inl::Int<0x102>{}), m2, a3);
-        const int f = (meta >> 16) - 1;  // the filter, on the first lane of its run; -1 elsewhere
-        const float vals[4] = {a0, a1, a2, a3};
-        TOUT *dst = obase + col0 + (f < 0 ? 0 : f);
-#pragma unroll
-        for (int gg = 0; gg < 4; ++gg) {
-          float v = vals[gg];
-          // max(val, floor) as Python evaluates it: a NaN stays a NaN (compute.py:459)
-          if (p.use_log) v = fast_log(p.log_floor > v ? p.log_floor : v);
-#if PDS_NT_STORE & 2
-          if (DLT == 0 && f >= 0 && gg < frames_here) __builtin_nontemporal_store((TOUT)v, dst + (int64_t)gg * p.out_stride);
-#else
-          if (DLT == 0 && f >= 0 && gg < frames_here) dst[(int64_t)gg * p.out_stride] = (TOUT)v;
-#endif
-          logged[gg] = v;
-        }
-      };
-      if constexpr (DLT == 0) {
-        float unused[4];
-        for (int rd = 0; rd < p.seg_rounds; ++rd) round_body(rd, unused);
-#if PDS_PF_WINAT == 1
-        read_window();  // (WINLDS: the next item's window slice)
-#endif
-      } else {
-        // the chunk's logged coefficients: the lane's filter of every round, the energies on their lane
-        float cur[DR][4];
-#pragma unroll
-        for (int rd = 0; rd < DR; ++rd) {
-#pragma unroll
-          for (int q = 0; q < 4; ++q) cur[rd][q] = 0.0f;
-          if (rd < p.seg_rounds) round_body(rd, cur[rd]);
-          if (p.dl_eslot == rd * 64 + lane) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-              cur[rd][q] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(e_keep), 16 * q));
-          }
-        }
-        if (chunk == 0) {  // frames in front of the utterance repeat its first frame
-#pragma unroll
-          for (int rd = 0; rd < DR; ++rd)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) Wc[rd][q] = cur[rd][0];
-        }
-        if (chunk > e_lo) emit_rows(chunk - 1, cur);
-#pragma unroll
-        for (int rd = 0; rd < DR; ++rd)
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            Wp[rd][q] = Wc[rd][q];
-            Wc[rd][q] = cur[rd][q];
-          }
-        ++chunk;
-      }
-      PDS_STAMP(5, 0);  // filter walk
-      if constexpr (PDS_STAGGER) __builtin_amdgcn_s_barrier();
-      wave_sync();
-      continue;
-    }
-    if constexpr (SEG) {
-      static_assert(!SEG || ELL_LDS, "segmented walks: tables in LDS");
-      static_assert(SEG != 2 || G::GROUPS == 4, "matrix-pipe segment walk: four frames per wave");
-      {
-        // Segmented walk for dense banks.  The rows of all filters are cut into segments of
-        // seg_len bins and dealt to the 64 lanes, seg_rounds segments each; a lane reads a
-        // segment's weights ONCE and applies them to all four frames of the wave (one 16-byte
-        // weight read per four 16-byte power reads instead of one per one, and no lane waits for
-        // a longer row than its own: every segment has the same length).  Partial sums go to the
-        // part of the wave's area that P leaves free; then lane f adds up filter f's segments for
-        // the four frames and stores four coefficients (64 consecutive floats per store).
-        float4 *part = reinterpret_cast<float4 *>(wbase + G::GROUPS * PSTR);
-        constexpr int SEG_DEPTH = N >= PDS_SEG_DEEP_N ? 4 : 2;
-        const int steps = p.seg_len >> 2;
-        if constexpr (SEG == 2) {
-          // Matrix-pipe form (mseg_tables.h): the filters in quads of four neighbours, a quad's bin range
-          // in units of seg_len bins, 16 units per round -- one per block of v_mfma_f32_4x4x1_16B_f32.
-          // Lane 4 b + i supplies the weight of filter i of block b's quad, lane 4 b + j the power of
-          // frame j, and lane 4 b + j receives the block's four filter sums for frame j: 256 exact
-          // float32 multiply-adds per instruction on the pipe the kernel leaves idle otherwise, for one
-          // 16-byte weight read and one 16-byte power read per four of them (the segmented walk below:
-          // five reads and sixteen vector multiply-adds per four bins of ONE filter).  Two accumulators
-          // take the bins alternately, so an instruction does not wait for the one before.
-          const int blk = lane >> 2, fr = lane & 3;
-          const float *Pj = wbase + fr * PSTR;
-          float *pf = reinterpret_cast<float *>(part) + fr;
-          // A round: ALL its operand reads (two 16-byte reads per four bins), then its matrix instructions;
-          // the reads of the NEXT round are issued before this round's instructions (two operand buffers),
-          // and a round's first bin is fetched two rounds ahead -- so neither an LDS round trip nor the
-          // table look-up in front of it is exposed per round.  (Measured at 1.5 waves per SIMD, Gammatone-64
-          // at N = 1024: reads and instructions of one round back to back take ~950 cycles per round for
-          // ~260 cycles of matrix pipe.)
-          const float4 *wbase4 = reinterpret_cast<const float4 *>(ellw_lds) + lane;
-          const int last = p.seg_rounds - 1;
-          auto meta_of = [&](int rd) { return meta_lds[(rd < last ? rd : last) * 16 + blk]; };
-          auto walk = [&](auto steps_c) {
-            constexpr int ST = decltype(steps_c)::value;
-            auto fetch = [&](float4 (&w)[ST], float4 (&x)[ST], const int rd, const int first) {
-              const float4 *wrow = wbase4 + __mul24(rd, ST) * 64;
-              const float4 *prow = reinterpret_cast<const float4 *>(Pj + first);
-#pragma unroll
-              for (int u = 0; u < ST; ++u) {
-                w[u] = wrow[u * 64];
-                x[u] = prow[u];
-              }
-            };
-            auto compute = [&](const float4 (&w)[ST], const float4 (&x)[ST], const int rd) {
-              f32x4 acc0 = {0.0f, 0.0f, 0.0f, 0.0f}, acc1 = {0.0f, 0.0f, 0.0f, 0.0f};
-#pragma unroll
-              for (int u = 0; u < ST; ++u) {
-                acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(w[u].x, x[u].x, acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(w[u].y, x[u].y, acc1, 0, 0, 0);
-                acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(w[u].z, x[u].z, acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(w[u].w, x[u].w, acc1, 0, 0, 0);
-              }
-              // partial slot = unit * 4 + filter of the quad, a float4 over the frames
-              float *dst = pf + (rd * 16 + blk) * 16;
-              dst[0] = acc0[0] + acc1[0];
-              dst[4] = acc0[1] + acc1[1];
-              dst[8] = acc0[2] + acc1[2];
-              dst[12] = acc0[3] + acc1[3];
-            };
-            // (two buffers of 16 bins: 64 registers, which the 256-register geometries have; the others,
-            // and longer units, run one round at a time)
-            if constexpr (ST == 4 && MINW <= 2) {
-              float4 wa[ST], xa[ST], wb[ST], xb[ST];
-              int fb = meta_of(1), fc = meta_of(2);
-              fetch(wa, xa, 0, meta_of(0));
-#pragma unroll 1
-              for (int rd = 0; rd <= last; rd += 2) {
-                const int fd = meta_of(rd + 3), fe = meta_of(rd + 4);
-                if (rd < last) fetch(wb, xb, rd + 1, fb);
-                compute(wa, xa, rd);
-                if (rd >= last) break;
-                if (rd + 1 < last) fetch(wa, xa, rd + 2, fc);
-                compute(wb, xb, rd + 1);
-                fb = fd;
-                fc = fe;
-              }
-            } else {
-              int first = meta_of(0);
-#pragma unroll 1
-              for (int rd = 0; rd <= last; ++rd) {
-                const int next = meta_of(rd + 1);
-                float4 w[ST], x[ST];
-                fetch(w, x, rd, first);
-                compute(w, x, rd);
-                first = next;
-              }
-            }
-          };
-          if (steps == 4) {  // (mseg_tables.h builds units of 16 or 32 bins)
-            walk(inl::Int<4>{});
-          } else {
-            walk(inl::Int<8>{});
-          }
-        } else
-        for (int q = 0; q < p.seg_rounds; ++q) {
-          const int slot = q * 64 + lane;
-          const int first = meta_lds[slot];
-          const float4 *wrow = reinterpret_cast<const float4 *>(ellw_lds + __mul24(slot, p.seg_len + 4));
-          const float4 *pg[G::GROUPS];
-          float acc[G::GROUPS];
-#pragma unroll
-          for (int gg = 0; gg < G::GROUPS; ++gg) {
-            pg[gg] = reinterpret_cast<const float4 *>(wbase + gg * PSTR + first);
-            acc[gg] = 0.0f;
-          }
-          // (geometries with the 256-register budget keep twice as many reads in flight)
-#pragma unroll SEG_DEPTH
-          for (int i = 0; i < steps; ++i) {
-            const float4 w = wrow[i];
-            float4 x[G::GROUPS];
-#pragma unroll
-            for (int gg = 0; gg < G::GROUPS; ++gg) x[gg] = pg[gg][i];
-#pragma unroll
-            for (int gg = 0; gg < G::GROUPS; ++gg) acc[gg] = fmaf(w.x, x[gg].x, acc[gg]);
-#pragma unroll
-            for (int gg = 0; gg < G::GROUPS; ++gg) acc[gg] = fmaf(w.y, x[gg].y, acc[gg]);
-#pragma unroll
-            for (int gg = 0; gg < G::GROUPS; ++gg) acc[gg] = fmaf(w.z, x[gg].z, acc[gg]);
-#pragma unroll
-            for (int gg = 0; gg < G::GROUPS; ++gg) acc[gg] = fmaf(w.w, x[gg].w, acc[gg]);
-          }
-          float *dst = reinterpret_cast<float *>(part) + slot * G::GROUPS;
-#pragma unroll
-          for (int gg = 0; gg < G::GROUPS; ++gg) dst[gg] = acc[gg];
-        }
-        if constexpr (PDS_STAMPS > 2) PDS_STAMP(4, 0);  // (diagnostic: the rounds go to slot 4, the sums and stores stay in 5)
-        wave_sync();
-        const int *fmeta = meta_lds + p.seg_rounds * (SEG == 2 ? 16 : 64);
-        constexpr int PSTEP = SEG == 2 ? 4 : 1;  // a filter's partial sums: consecutive slots, or a quad apart
-        for (int f = lane; f < p.num_filts; f += 64) {
-          const int fm = fmeta[f];
-          const float *src = reinterpret_cast<const float *>(part) + (fm & 0xffff) * G::GROUPS;
-          float sum[G::GROUPS];
-#pragma unroll
-          for (int gg = 0; gg < G::GROUPS; ++gg) sum[gg] = 0.0f;
-          if constexpr (PDS_MSEG_RED4) {
-            // (long rows have ten and more partial sums: four reads in flight per pass instead of a round
-            // trip per partial; reads past the filter's last partial re-read it and are masked out)
-            const int cnt = fm >> 16;
-            for (int k = 0; k < cnt; k += 4) {
-              float v[4][G::GROUPS];
-#pragma unroll
-              for (int u = 0; u < 4; ++u) {
-                const float *at = src + G::GROUPS * PSTEP * (k + u < cnt ? k + u : cnt - 1);
-                if constexpr (G::GROUPS == 4) {
-                  const float4 t = *reinterpret_cast<const float4 *>(at);
-                  v[u][0] = t.x, v[u][1] = t.y, v[u][2] = t.z, v[u][3] = t.w;
-                } else if constexpr (G::GROUPS == 2) {
-                  const float2 t = *reinterpret_cast<const float2 *>(at);
-                  v[u][0] = t.x, v[u][1] = t.y;
-                } else {
-#pragma unroll
-                  for (int gg = 0; gg < G::GROUPS; ++gg) v[u][gg] = at[gg];
-                }
-              }
-#pragma unroll
-              for (int u = 0; u < 4; ++u) {
-                const bool live = k + u < cnt;
-#pragma unroll
-                for (int gg = 0; gg < G::GROUPS; ++gg) sum[gg] += live ? v[u][gg] : 0.0f;
-              }
-            }
-          } else
-          for (int k = fm >> 16; k > 0; --k) {
-#pragma unroll
-            for (int gg = 0; gg < G::GROUPS; ++gg) sum[gg] += src[gg];
-            src += PSTEP * G::GROUPS;
-          }
-#pragma unroll
-          for (int gg = 0; gg < G::GROUPS; ++gg) {
-            float v = sum[gg];
-            // max(val, floor) as Python evaluates it: a NaN stays a NaN (compute.py:459)
-            if (p.use_log) v = fast_log(p.log_floor > v ? p.log_floor : v);
-            if (gg < frames_here) obase[(int64_t)gg * p.out_stride + col0 + f] = (TOUT)v;
-          }
-        }
-        PDS_STAMP(5, 0);  // filter walk
-      if constexpr (PDS_STAGGER) __builtin_amdgcn_s_barrier();
-        wave_sync();
-        continue;
-      }
-    }
-#pragma unroll
-    for (int sl = 0; sl < USLOTS; ++sl)
-      if (sl < p.ell_slots) run_slot(metas[sl], slot_len[sl], slot_woff[sl]);
-    for (int sl = USLOTS; sl < p.ell_slots; ++sl)
-      run_slot(meta_lds[sl * N2 + r], load_const(p.ell_len + sl), load_const(p.ell_woff + sl));
-    PDS_STAMP(5, 0);  // filter walk
-      if constexpr (PDS_STAGGER) __builtin_amdgcn_s_barrier();
-    wave_sync();
-  }
-  if constexpr (PDS_STAMPS) {
-    if (p.stamps && lane == 0) {
-      // [0..5] phase sums, [6] items, [7] bookkeeping, then absolute times: kernel entry, loop start, loop end
-      unsigned long long *dst = p.stamps + ((size_t)blockIdx.x * p.waves + wave) * 12;
-#pragma unroll
-      for (int i = 0; i < 8; ++i) dst[i] = st_acc[i];
-      dst[8] = st_entry;
-      dst[9] = st_loop;
-      dst[10] = __builtin_readcyclecounter();
-    }
-  }
-}
-
-// ----------------------------------------------------------------------- host side ---
-
-// transform sizes with float64-input instantiations of the fused kernel
-constexpr bool fast_f64in_kind(int n) { return n == 256 || n == 512 || n == 1024 || n == 2048; }
+extern "C" __attribute__((visibility("default"))) int32_t pds_build_experiments(void) { return PDS_EXPERIMENTS ? 1 : 0; }
 
 bool fast_has_f64in(const pds_stft_plan *plan) { return plan->fast.kind && fast_f64in_kind(plan->fast.kind); }
-
-// transform sizes with fused statics + deltas instantiations (16-lane geometries)
-constexpr bool fast_deltas_kind(int n) { return n == 512 || n == 1024; }
 
 bool fast_has_fused_deltas(const pds_stft_plan *plan) {
   const FastTables &ft = plan->fast;
@@ -1867,360 +45,35 @@ __global__ __launch_bounds__(1024) void chunk_prefix_kernel(const int64_t *nfram
   if (threadIdx.x == 1023) prefix[B] = part[1023];
 }
 
-template <int N1, int N2, int NROWS, int MINW>
-static int32_t launch_wave(const pds_stft_plan *plan, const BatchArgs &a) {
-  using G = WaveGeom<N1, N2, NROWS>;
-  // resident waves per CU that the register budget allows; the fused statics + deltas instantiations
-  // hold their window in registers and run three waves per SIMD where the others run four
-  constexpr int DMINW = MINW > 3 ? 3 : MINW;
-  constexpr int CU_WAVES_STFT = 4 * MINW;
-  const int CU_WAVES = a.dl_K > 0 ? 4 * DMINW : CU_WAVES_STFT;
-  const FastTables &ft = plan->fast;
-  FastParams p;
-  p.sig = a.d_signal;
-  p.offsets = a.d_offsets;
-  p.lengths = a.d_lengths;
-  p.nframes = a.d_nframes;
-  p.row_off = a.d_row_off;
-  p.out = a.d_out;
-  p.out_stride = a.out_stride;
-  p.win_lane = ft.d_window;
-  p.tw_lane = (const float2 *)ft.d_twiddle;
-  p.tw_special = (const float2 *)ft.d_tw_special;
-  p.win_half = nullptr;
-  p.tw_seed = nullptr;
-  p.ell_w = ft.d_ell_w;
-  p.ell_meta = ft.d_ell_meta;
-  p.ell_len = ft.d_ell_len;
-  p.ell_woff = ft.d_ell_woff;
-  p.ell_wfloats = ft.ell_wfloats;
-  p.ell_slots = ft.ell_slots;
-  p.L = plan->d.frame_length;
-  p.S = plan->d.frame_shift;
-  p.pad_left = a.pad_left;
-  p.include_energy = plan->d.include_energy;
-  p.use_power = plan->d.use_power;
-  p.use_log = plan->d.use_log;
-  p.log_floor = (float)plan->d.log_floor;
-  p.inv_L = 1.0f / (float)plan->d.frame_length;
-  p.num_utts = a.B;
-  const int64_t chunks = (a.max_frames + G::GROUPS - 1) / G::GROUPS;
-  if (chunks * a.B > 0x7fffffff || chunks > 0x3fffffff || a.out_stride * G::GROUPS > (a.out_f64 ? 0x0fffffff : 0x1fffffff) ||
-      a.max_frames * plan->d.frame_shift > 0x7fffffff) {
-    set_error("stft_batch: too many frame chunks in one call");
-    return PDS_ERR_INVALID;
-  }
-  p.chunks_per_utt = (int)chunks;
-  // LDS per workgroup: one exchange area per wave, the small tables, and the filter weight
-  // rows when they fit.  Workgroup shapes in order of preference -- all CU_WAVES resident as two
-  // workgroups, as one workgroup (one copy of the table instead of two), then fewer resident waves
-  // with the table still in LDS (measured on the 38 KB gammatone table at N = 1024: 6 waves with
-  // LDS weights beat 8 waves reading them through L1/L2 by 33 %).  Tables too large even for that
-  // stay in global memory.
-  const size_t lds_cu = 160 * 1024;
-  const size_t per_wave = (size_t)G::EXCH_F2 * 8;
-  int shapes[4][2] = {{CU_WAVES / 2, 2}, {CU_WAVES, 1}, {CU_WAVES * 3 / 4, 1}, {CU_WAVES * 5 / 8, 1}};
-#ifdef PDS_ONE_WG  // (experiment: one workgroup per CU whatever fits)
-  shapes[0][0] = CU_WAVES, shapes[0][1] = 1;
-#endif
-  if (CU_WAVES % 8 != 0) {
-    // (three waves per SIMD: two workgroups of six waves do not tile the four SIMDs -- the second one of a
-    // CU waited for the first to finish, measured as a launch twice as long -- one of twelve does)
-    shapes[0][0] = CU_WAVES, shapes[0][1] = 1;
-    shapes[1][0] = CU_WAVES * 2 / 3, shapes[1][1] = 1;
-    shapes[2][0] = CU_WAVES / 3, shapes[2][1] = 1;
-    shapes[3][0] = CU_WAVES / 3, shapes[3][1] = 1;
-  }
-  constexpr int CU_WAVES_K = CU_WAVES_STFT;  // launch bound of the instantiations below
-  int waves = CU_WAVES / 2, wgs_per_cu = 2;
-  bool in_lds = false;
-  // Filter walk: the plan's preferred one (fast_tables_create: fewest 16-byte LDS reads per item, or
-  // PDS_STFT_WALK) when its tables fit in LDS beside the waves' areas, else the next: row segments
-  // (2), segments of dense banks (1), ELL (0; its tables may also stay in global memory).
-  p.seg_rounds = 0;
-  p.seg_len = 0;
-  p.num_filts = plan->d.num_filts;
-  const bool pre = a.preemph != 0.0;
-  int walk = 0;
-  // (fused deltas exist for the row-segment walk only: take it whatever the plan prefers)
-  const bool dl = a.dl_K > 0 && ft.rsn_rounds > 0;  // (its own table: numbered order)
-  // prefetch instantiation (PF): 32 x 16 geometry with the row-segment walk, float32 samples, round-robin
-  // scheduling (PDS_STFT_PF=0 keeps the kernel without it)
-  constexpr bool PFG = N1 == 32 && N2 == 16;
-  const char *pf_env = std::getenv("PDS_STFT_PF");
-  const bool pf_ok = PDS_EXPERIMENTS && PFG && !pre && !a.in_f64 && !a.stretch && a.dl_K == 0 && ft.d_win_half &&
-                     ft.d_tw_seed && !(pf_env && pf_env[0] == '0');
-  constexpr int PF_WSTR = ((NROWS + 3) & ~3) % 8 == 4 ? ((NROWS + 3) & ~3) : ((NROWS + 3) & ~3) + 4;
-  const size_t pf_extra = (PDS_PF_WIN == 1) ? (size_t)N2 * PF_WSTR * 4 : 0;  // window table in LDS
-  constexpr bool MSG = G::GROUPS == 4 && inl::is_pow2(N1);  // matrix-pipe segment walk instantiated
-  constexpr bool SEGOK = G::GROUPS == 4 || (inl::is_pow2(N1) && N2 >= 32);  // segmented walk instantiated
-  for (int cand = (G::GROUPS == 4) ? (dl ? 2 : ft.walk) : (SEGOK && ft.walk == 1 ? 1 : 0); cand >= 0 && !in_lds; --cand) {
-    if (cand == 3 && (!MSG || ft.ms_rounds == 0 || pre || a.in_f64)) continue;
-    // (no segmented variant of the fused pre-emphasis kernel)
-    if ((cand == 2 && !dl && ft.rs_rounds == 0) || (cand == 1 && (ft.seg_rounds == 0 || pre || a.in_f64))) continue;
-    const int meta_ints = cand == 3 ? ft.ms_meta_ints : cand == 2 ? (dl ? ft.rsn_rounds : ft.rs_rounds) * 64 : cand == 1 ? ft.seg_meta_ints : ft.ell_slots * N2;
-    const int meta_pad = (std::max(meta_ints, USLOTS * N2) + 3) / 4 * 4;
-    const size_t fixed = (size_t)N2 * 8 + (size_t)meta_pad * 4 + (cand == 2 && pf_ok ? pf_extra : 0);
-    const size_t table_bytes = (size_t)(cand == 3 ? ft.ms_wfloats : cand == 2 ? (dl ? ft.rsn_wfloats : ft.rs_wfloats) : cand == 1 ? ft.seg_wfloats : ft.ell_wfloats) * 4;
-    // (segment sums live behind P in the wave's area)
-    if (cand == 1 && (size_t)G::GROUPS * G::PSTR * 4 + (size_t)ft.seg_rounds * 64 * 4 * G::GROUPS > per_wave) continue;
-    if (cand == 3 && (size_t)G::GROUPS * G::PSTR * 4 + (size_t)ft.ms_rounds * 64 * 16 > per_wave) continue;
-    for (const auto &shape : shapes)
-      if (shape[0] * per_wave + fixed + table_bytes + 32 <= lds_cu / shape[1]) {  // (+ the ticket counter)
-        waves = shape[0];
-        wgs_per_cu = shape[1];
-        in_lds = true;
-        break;
-      }
-    p.ell_meta_pad = meta_pad;
-    p.ell_meta_ints = meta_ints;
-    if (in_lds && cand == 3) {
-      p.ell_w = ft.d_ms_w;
-      p.ell_meta = ft.d_ms_meta;
-      p.ell_wfloats = ft.ms_wfloats;
-      p.seg_rounds = ft.ms_rounds;
-      p.seg_len = ft.ms_len;
-    } else if (in_lds && cand == 1) {
-      p.ell_w = ft.d_seg_w;
-      p.ell_meta = ft.d_seg_meta;
-      p.ell_wfloats = ft.seg_wfloats;
-      p.seg_rounds = ft.seg_rounds;
-      p.seg_len = ft.seg_len;
-    } else if (in_lds && cand == 2) {
-      p.ell_w = dl ? ft.d_rsn_w : ft.d_rs_w;
-      p.ell_meta = dl ? ft.d_rsn_meta : ft.d_rs_meta;
-      p.ell_wfloats = dl ? ft.rsn_wfloats : ft.rs_wfloats;
-      p.seg_rounds = dl ? ft.rsn_rounds : ft.rs_rounds;
-      p.seg_len = dl ? ft.rsn_len : ft.rs_len;
-    }
-    if (in_lds) walk = cand;
-  }
-#ifdef PDS_FORCE_WAVES  // (experiment: throughput against resident waves per CU, two workgroups per CU)
-  if (in_lds && PDS_FORCE_WAVES <= CU_WAVES / 2) waves = PDS_FORCE_WAVES, wgs_per_cu = 2;
-#endif
-  const size_t fixed = (size_t)N2 * 8 + (size_t)p.ell_meta_pad * 4 + (walk == 2 && in_lds && pf_ok ? pf_extra : 0);
-  const size_t table_bytes = (size_t)p.ell_wfloats * 4;
-  // the fused pre-emphasis variant exists for LDS-resident tables only; the rare other case
-  // (dense complex bank at N >= 1024 plus pre-emphasis) takes the direct-DFT kernel
-  if (pre && !in_lds) return launch_stft_generic_f32(plan, a);
-  p.preemph = (float)a.preemph;
-  p.preemph_d = a.preemph;
-  p.waves = waves;
-  p.mf_tab = ft.d_mf_tab;
-#if PDS_STAMPS
-  p.stamps = g_stamp_buf;
-#else
-  p.stamps = nullptr;
-#endif
-  size_t smem = waves * per_wave + fixed + (in_lds ? table_bytes : 0);
-  smem = (smem + 15) & ~(size_t)15;
-  p.lds_ticket_off = (int)(smem / 4);  // the workgroup's ticket counter
-  smem += 16;
-  p.waves_rcp = (unsigned)((0x100000000ull + (unsigned)waves - 1) / (unsigned)waves);
-  {
-    const char *dyn_env = std::getenv("PDS_STFT_DYN");
-    p.dyn = (dyn_env && dyn_env[0] == '0') ? 0 : 1;
-  }
-  constexpr bool W4 = G::GROUPS == 4;  // the walks over four frames exist for the 16-lane geometries
-  const bool seg = SEGOK && (walk == 1 || walk == 3), rsg = W4 && walk == 2, mseg = MSG && walk == 3;
-  auto kern = pre      ? (rsg ? stft_wave_kernel<N1, N2, NROWS, CU_WAVES_K, MINW, true, true, false, 0, W4>
-                              : stft_wave_kernel<N1, N2, NROWS, CU_WAVES_K, MINW, true, true>)
-              : rsg    ? stft_wave_kernel<N1, N2, NROWS, CU_WAVES_K, MINW, true, false, false, 0, W4>
-              : mseg   ? stft_wave_kernel<N1, N2, NROWS, CU_WAVES_K, MINW, true, false, MSG ? 2 : 0>
-              : seg    ? stft_wave_kernel<N1, N2, NROWS, CU_WAVES_K, MINW, true, false, SEGOK ? 1 : 0>
-              : in_lds ? stft_wave_kernel<N1, N2, NROWS, CU_WAVES_K, MINW, true, false>
-                       : stft_wave_kernel<N1, N2, NROWS, CU_WAVES_K, MINW, false, false>;
-  // matrix-pipe front end: the 32 x 16 geometry with LDS-resident filter tables, when the plan has
-  // its tables for this row count
-  constexpr int MFS = (N1 == 32 && N2 == 16) ? mfma_front_steps(NROWS) : 0;
-  bool mf = false;
-  if constexpr (MFS > 0) {
-    if (in_lds && ft.d_mf_tab && ft.mf_rows == NROWS && !mseg) {
-      mf = true;
-      kern = pre   ? (rsg ? stft_wave_kernel<N1, N2, NROWS, CU_WAVES_K, MINW, true, true, false, MFS, W4>
-                          : stft_wave_kernel<N1, N2, NROWS, CU_WAVES_K, MINW, true, true, false, MFS>)
-             : rsg ? stft_wave_kernel<N1, N2, NROWS, CU_WAVES_K, MINW, true, false, false, MFS, W4>
-             : seg ? stft_wave_kernel<N1, N2, NROWS, CU_WAVES_K, MINW, true, false, W4, MFS>
-                   : stft_wave_kernel<N1, N2, NROWS, CU_WAVES_K, MINW, true, false, false, MFS>;
-    }
-  }
-  bool pf_used = false;
-#if PDS_EXPERIMENTS
-  if constexpr (PFG) {
-    if (pf_ok && rsg && in_lds && !mf) {
-      pf_used = true;
-      kern = stft_wave_kernel<N1, N2, NROWS, CU_WAVES_K, MINW, true, false, 0, 0, W4, float, float, 0, false, PFG>;
-      p.win_half = ft.d_win_half;
-      p.tw_seed = (const float2 *)ft.d_tw_seed;
-    }
-  }
-#endif
-  // ragged batches (pds_stft_batch_ragged_f32): the same kernels with stretch scheduling (STR); float32 samples
-  // without fused pre-emphasis, in-lane front end
-  bool str_used = false;
-  if (a.stretch && !pre && !a.in_f64 && a.dl_K == 0 && !mf && a.d_chunk_prefix) {
-    str_used = true;
-    kern = rsg      ? stft_wave_kernel<N1, N2, NROWS, CU_WAVES_K, MINW, true, false, 0, 0, W4, float, float, 0, true>
-           : mseg   ? stft_wave_kernel<N1, N2, NROWS, CU_WAVES_K, MINW, true, false, MSG ? 2 : 0, 0, false, float, float, 0, true>
-           : seg    ? stft_wave_kernel<N1, N2, NROWS, CU_WAVES_K, MINW, true, false, SEGOK ? 1 : 0, 0, false, float, float, 0, true>
-           : in_lds ? stft_wave_kernel<N1, N2, NROWS, CU_WAVES_K, MINW, true, false, 0, 0, false, float, float, 0, true>
-                    : stft_wave_kernel<N1, N2, NROWS, CU_WAVES_K, MINW, false, false, 0, 0, false, float, float, 0, true>;
-    p.chunk_prefix = a.d_chunk_prefix;
-  }
-  // float64 samples (pds_stft_batch_f64in): the common power-of-two geometries, LDS-resident tables,
-  // ELL or row-segment walk; float64 features without fused pre-emphasis only
-  int f64_which = -1;
-  if (a.in_f64) {
-    constexpr bool F64IN = fast_f64in_kind(N1 * N2);
-    if constexpr (F64IN) {
-      if (!in_lds || (a.out_f64 && pre)) {
-        set_error("stft_batch_f64in: not served for this plan (filter table outside LDS, or float64 features with fused pre-emphasis)");
-        return PDS_ERR_INVALID;
-      }
-      mf = false;
-      if (a.out_f64)
-        kern = rsg ? stft_wave_kernel<N1, N2, NROWS, CU_WAVES_K, MINW, true, false, false, 0, W4, double, double>
-                   : stft_wave_kernel<N1, N2, NROWS, CU_WAVES_K, MINW, true, false, false, 0, false, double, double>;
-      else if (pre)
-        kern = rsg ? stft_wave_kernel<N1, N2, NROWS, CU_WAVES_K, MINW, true, true, false, 0, W4, double, float>
-                   : stft_wave_kernel<N1, N2, NROWS, CU_WAVES_K, MINW, true, true, false, 0, false, double, float>;
-      else
-        kern = rsg ? stft_wave_kernel<N1, N2, NROWS, CU_WAVES_K, MINW, true, false, false, 0, W4, double, float>
-                   : stft_wave_kernel<N1, N2, NROWS, CU_WAVES_K, MINW, true, false, false, 0, false, double, float>;
-      f64_which = 12 + (a.out_f64 ? 4 : pre ? 2 : 0) + (rsg ? 1 : 0);
-    } else {
-      set_error("stft_batch_f64in: no fused float64-input kernel for this transform size");
-      return PDS_ERR_INVALID;
-    }
-  }
-  // fused statics + deltas (pds_stft_deltas_batch_f32): row-segment walk with at most two rounds and
-  // a spare lane for the energy, see the kernel
-  int dl_which = -1;
-  if (a.dl_K > 0) {
-    constexpr bool DELTAS = fast_deltas_kind(N1 * N2) && G::GROUPS == 4;
-    if constexpr (DELTAS) {
-      const int staged = ((a.dl_K + 1) * (plan->d.num_filts + (plan->d.include_energy ? 1 : 0)) + 3) / 4 * 16 + 64;  // floats
-      if (!in_lds || pre || a.in_f64 || !rsg || !dl || ft.rsn_rounds > 2 || (plan->d.include_energy && ft.rs_eslot < 0) ||
-          staged > G::EXCH_F2 * 2) {
-        set_error("stft_deltas_batch: not served for this plan and call (needs the row-segment filter walk with at "
-                  "most two rounds in LDS, float32 samples, no fused pre-emphasis)");
-        return PDS_ERR_INVALID;
-      }
-      mf = false;
-      kern = a.dl_K == 1 ? stft_wave_kernel<N1, N2, NROWS, 4 * DMINW, DMINW, true, false, false, 0, true, float, float, 1>
-                         : stft_wave_kernel<N1, N2, NROWS, 4 * DMINW, DMINW, true, false, false, 0, true, float, float, 2>;
-      dl_which = 18 + (a.dl_K - 1);
-      for (int j = 0; j < 5; ++j) p.dl_f1[j] = (float)a.dl_taps[j];
-      for (int j = 0; j < 9; ++j) p.dl_f2[j] = a.dl_K > 1 ? (float)a.dl_taps[5 + j] : 0.0f;
-      p.dl_inner = plan->d.num_filts + (plan->d.include_energy ? 1 : 0);
-      p.dl_eslot = plan->d.include_energy ? ft.rs_eslot : -1;
-      p.chunk_prefix = a.d_chunk_prefix;
-      p.dl_debug = std::getenv("PDS_DL_DEBUG") ? std::atoi(std::getenv("PDS_DL_DEBUG")) : 0;
-    } else {
-      set_error("stft_deltas_batch: no fused kernel for this transform size");
-      return PDS_ERR_INVALID;
-    }
-  }
-  // the dynamic-LDS limit is an attribute of the kernel on one device: raised once per
-  // (instantiation, device, variant) and remembered (relaxed atomics: a lost race repeats the call)
-  constexpr int kDevices = 64;
-  static std::atomic<size_t> attr_smem[kDevices][32];
-  const int which = dl_which >= 0    ? dl_which
-                    : f64_which >= 0 ? f64_which
-                    : pf_used        ? 27
-                    : str_used       ? 22 + (rsg ? 0 : mseg ? 1 : seg ? 2 : in_lds ? 3 : 4)
-                    : mseg           ? 20
-                                     : (pre ? (rsg ? 5 : 2) : rsg ? 4 : seg ? 3 : (in_lds ? 1 : 0)) + (mf ? 6 : 0);
-  const bool cached = plan->device >= 0 && plan->device < kDevices;
-  if (!cached || smem > attr_smem[plan->device][which].load(std::memory_order_relaxed)) {
-    PDS_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)smem));
-    if (cached) attr_smem[plan->device][which].store(smem, std::memory_order_relaxed);
-  }
-  int64_t grid = (int64_t)ft.num_cus * wgs_per_cu;
-  const int64_t need = (chunks * a.B + waves - 1) / waves;
-  if (grid > need) grid = need;
-  const int64_t grid_waves = grid * waves;
-  p.step_utts = (int)(grid_waves / chunks);
-  p.step_chunks = (int)(grid_waves % chunks);
-  if (a.dl_K > 0 || str_used) {
-    // the utterances' chunk counts summed up on the device, then one stretch of chunks per wave
-    grid = std::min<int64_t>((int64_t)ft.num_cus * wgs_per_cu, std::max<int64_t>(1, (chunks * a.B + 4 * waves - 1) / (4 * waves)));
-    hipLaunchKernelGGL(chunk_prefix_kernel, dim3(1), dim3(1024), 0, a.stream, a.d_nframes, a.B, G::GROUPS,
-                       a.d_chunk_prefix);
-    PDS_HIP(hipGetLastError());
-  }
-  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(waves * 64), smem, a.stream, p);
+int32_t launch_chunk_prefix(const int64_t *d_nframes, int B, int groups, int64_t *d_prefix, hipStream_t stream) {
+  hipLaunchKernelGGL(chunk_prefix_kernel, dim3(1), dim3(1024), 0, stream, d_nframes, B, groups, d_prefix);
   PDS_HIP(hipGetLastError());
   return PDS_OK;
 }
 
-// Instantiated geometries.  N -> (N1, N2); row counts cover the common frame lengths exactly
-// (e.g. 25 ms @ 16 kHz = 400 samples = 25 rows of 16) and round other lengths up.
-//   N = 128 : 16 x 8      N = 256 : 32 x 8      N = 512 : 32 x 16
-//   N = 1024: 64 x 16     N = 2048: 64 x 32     N = 4096: 64 x 64 (one frame per wavefront)
-// Transforms without zero padding (N = L, every row in use), N1 x N2:
-//   160: 20 x 8    200: 25 x 8    240: 30 x 8    320: 20 x 16   400: 25 x 16   480: 30 x 16
-//   640: 20 x 32   800: 25 x 32   960: 30 x 32
-#define PDS_GEOM_ROWS(N1, N2, R, MINW) \
-  if (rows <= R) return launch_wave<N1, N2, R, MINW>(plan, a);
+// The instantiated geometries (stft_geoms.def), one launcher each, defined in its own object file
+#define PDS_GEOM(N1, N2, R, MINW) int32_t launch_geom_##N1##_##N2##_##R(const pds_stft_plan *plan, const BatchArgs &a);
+#ifdef PDS_DEV_ONLY512
+PDS_GEOM(32, 16, 25, 4)
+#else
+#include "stft_geoms.def"
+#endif
+#undef PDS_GEOM
 
 int32_t launch_stft_fast_f32(const pds_stft_plan *plan, const BatchArgs &a) {
-  const int rows = plan->fast.rows;
-#ifdef PDS_DEV_ONLY512  // (ISA inspection builds: the headline instantiations alone)
-#ifndef PDS_DEV_MINW
-#define PDS_DEV_MINW 4
-#endif
-  if (plan->fast.kind == 512 && rows <= 25) return launch_wave<32, 16, 25, PDS_DEV_MINW>(plan, a);
-  set_error("stft_batch: development build");
-  return PDS_ERR_INVALID;
+  const FastTables &ft = plan->fast;
+  // the smallest row count of the plan's (N1, N2) that holds the frame
+#define PDS_GEOM(N1, N2, R, MINW) \
+  if (ft.n1 == N1 && ft.n2 == N2 && ft.rows <= R) return launch_geom_##N1##_##N2##_##R(plan, a);
+#ifdef PDS_DEV_ONLY512  // (ISA inspection and variant builds: the headline geometry alone)
+  PDS_GEOM(32, 16, 25, 4)
 #else
-  switch (plan->fast.kind) {
-    case 128:
-      PDS_GEOM_ROWS(16, 8, 10, 4) PDS_GEOM_ROWS(16, 8, 13, 4) PDS_GEOM_ROWS(16, 8, 16, 4)
-      break;
-    case 256:
-      PDS_GEOM_ROWS(32, 8, 20, 4) PDS_GEOM_ROWS(32, 8, 25, 4) PDS_GEOM_ROWS(32, 8, 28, 4)
-      PDS_GEOM_ROWS(32, 8, 32, 4)
-      break;
-    case 512:
-      PDS_GEOM_ROWS(32, 16, 20, 4) PDS_GEOM_ROWS(32, 16, 25, 4) PDS_GEOM_ROWS(32, 16, 28, 4)
-      PDS_GEOM_ROWS(32, 16, 30, 4) PDS_GEOM_ROWS(32, 16, 32, 4)
-      break;
-    case 1024:
-      if (plan->fast.n2 == 32) {
-        // (three waves per SIMD: 168 registers -- at 128 the 30-row form spills 33 dwords -- and the dense banks this
-        // geometry is for leave room for twelve waves per CU beside their tables anyway)
-        PDS_GEOM_ROWS(32, 32, 24, 3) PDS_GEOM_ROWS(32, 32, 30, 3) PDS_GEOM_ROWS(32, 32, 32, 3)
-        break;
-      }
-      PDS_GEOM_ROWS(64, 16, 40, 2) PDS_GEOM_ROWS(64, 16, 50, 2)
-      PDS_GEOM_ROWS(64, 16, 60, 2) PDS_GEOM_ROWS(64, 16, 64, 2)
-      break;
-    case 2048:
-      PDS_GEOM_ROWS(64, 32, 35, 2) PDS_GEOM_ROWS(64, 32, 38, 2) PDS_GEOM_ROWS(64, 32, 48, 2)
-      PDS_GEOM_ROWS(64, 32, 64, 2)
-      break;
-    case 4096:  // one frame per wavefront, one wavefront per SIMD (512 registers)
-      PDS_GEOM_ROWS(64, 64, 38, PDS_N4096_MINW) PDS_GEOM_ROWS(64, 64, 48, 1) PDS_GEOM_ROWS(64, 64, 64, 1)
-      break;
-    case 160: PDS_GEOM_ROWS(20, 8, 20, 4) break;
-    case 200: PDS_GEOM_ROWS(25, 8, 25, 4) break;
-    case 240: PDS_GEOM_ROWS(30, 8, 30, 4) break;
-    case 320: PDS_GEOM_ROWS(20, 16, 20, 4) break;
-    case 400: PDS_GEOM_ROWS(25, 16, 25, 4) break;
-    case 480: PDS_GEOM_ROWS(30, 16, 30, 4) break;
-    case 640: PDS_GEOM_ROWS(20, 32, 20, 2) break;
-    case 800: PDS_GEOM_ROWS(25, 32, 25, 2) break;
-    case 960: PDS_GEOM_ROWS(30, 32, 30, 2) break;
-    default:
-      break;
-  }
+#include "stft_geoms.def"
+#endif
+#undef PDS_GEOM
   set_error("stft_batch: no fused kernel for this plan");
   return PDS_ERR_INVALID;
-#endif
 }
-#undef PDS_GEOM_ROWS
 
 int32_t fast_tables_create(pds_stft_plan *plan, const double *window, const int32_t *row_ptr,
                            const int32_t *col, const double *val) {
@@ -2240,7 +93,7 @@ int32_t fast_tables_create(pds_stft_plan *plan, const double *window, const int3
       // 0.335 ms per step) -- with two frames per wave its filter walk is the segmented one at three reads per
       // four bins, 3300 cycles per frame against 1300 for the matrix-pipe walk over four frames, which eats
       // what the transforms gain.  Opt-in.
-      const char *geom = std::getenv("PDS_N1024_GEOM");
+      const char *geom = PDS_EXPERIMENTS ? std::getenv("PDS_N1024_GEOM") : nullptr;  // (-DPDS_EXPERIMENTS=1 builds only)
       const bool wide = geom && std::strcmp(geom, "32x32") == 0;
       n1 = wide ? 32 : 64;
       n2 = wide ? 32 : 16;
@@ -2529,7 +382,7 @@ int32_t fast_tables_create(pds_stft_plan *plan, const double *window, const int3
   // instantiation launch_stft_fast_f32 picks.  Opt-in (PDS_STFT_FRONT=mfma) while the in-lane
   // transform measures faster (profiles/r2a_front_ab_counters.txt).
   {
-    const char *front = std::getenv("PDS_STFT_FRONT");
+    const char *front = PDS_EXPERIMENTS ? std::getenv("PDS_STFT_FRONT") : nullptr;  // (-DPDS_EXPERIMENTS=1 builds only)
     const int rows = (d.frame_length + n2 - 1) / n2;
     int bucket = 0;
     for (int b : {20, 25, 28, 30, 32})

@@ -549,6 +549,10 @@ def test_alternative_kernel_forms_match_the_oracle(switch, value, name, golden_m
     """The forms a plan does not pick by default -- matrix-pipe front end, each of the four filter walks --
     through the same ragged batch (switches are read when the plan is
     created, so the computer is built after the switch is set)"""
+    import pydrobert_speech_amd as ps
+
+    if switch in ("PDS_STFT_FRONT", "PDS_N1024_GEOM") and not ps._native.lib().pds_build_experiments():
+        pytest.skip("measured-and-rejected form: only in libraries built with make EXTRA=-DPDS_EXPERIMENTS=1")
     monkeypatch.setenv(switch, value)
     comp = alias_factory_subclass_from_arg(FrameComputer, json.loads(json.dumps(golden_meta["configs"][name])))
     p = oracle_params(golden_tables, name)

@@ -1,12 +1,13 @@
 #!/bin/bash
-# tools/isa_dev.sh [extra hipcc flags]: compiles the headline instantiations of stft_fast.hip alone
-# (-DPDS_DEV_ONLY512) with --save-temps into /tmp/isa and prints each kernel's resource usage.
+# tools/isa_dev.sh [extra hipcc flags]: compiles ONE geometry of the fused STFT kernel (ISA_GEOM="n1 n2 rows minw",
+# default the headline's "32 16 25 4") with --save-temps into /tmp/isa and prints each kernel's resource usage.
 set -e
 mkdir -p /tmp/isa && cd /tmp/isa
-src=/root/repo/pydrobert-speech_amd/csrc/stft_fast.hip
+read n1 n2 rows minw <<< "${ISA_GEOM:-32 16 25 4}"
+src=/root/repo/pydrobert-speech_amd/csrc/stft_geom.hip
 /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wall -Wno-unused-result -ffp-contract=fast \
-  -fno-signed-zeros -fno-slp-vectorize -DPDS_DEV_ONLY512 "$@" --save-temps -c $src -o /tmp/isa/dev.o 2>&1 | grep -v warning | head -20
-s=/tmp/isa/stft_fast-hip-amdgcn-amd-amdhsa-gfx950.s
+  -fno-signed-zeros -fno-slp-vectorize -DPDS_G_N1=$n1 -DPDS_G_N2=$n2 -DPDS_G_ROWS=$rows -DPDS_G_MINW=$minw "$@" --save-temps -c $src -o /tmp/isa/dev.o 2>&1 | grep -v warning | head -20
+s=/tmp/isa/stft_geom-hip-amdgcn-amd-amdhsa-gfx950.s
 python3 - $s <<'PY'
 import re, sys
 name = None
