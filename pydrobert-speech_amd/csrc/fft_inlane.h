@@ -190,18 +190,22 @@ PDS_HD void rdft_scaled(const float *a, float &even_sum, float &odd_sum, float *
   });
 }
 
-// The fifteen inter-stage twiddles W^k, k = 1..15, of one lane (W = e^{-2 pi i r / N}, a unit complex
-// number per lane) regenerated from three seeds w1 = W, w4 = W^4, w8 = W^8 instead of being held in
-// thirty registers: twelve complex products (48 instructions), none more than four products deep, so
-// a twiddle carries at most ~5 float32 roundings (tests/test_twiddle_chain.py replays this routine
-// against float64: max error 2e-7 over all lanes of the 32 x 16 geometry).  t[8] comes out DOUBLED:
-// the caller feeds rdft_scaled a window times 1/2, which makes that routine's outputs A[k] for
-// k != M/4 and A[M/4] / 2 (see rdft_scaled), so no twiddle needs a scale factor of its own.
+// The K inter-stage twiddles W^k, k = 1..K (K = 15 or 31), of one lane (W = e^{-2 pi i r / N}, a unit complex
+// number per lane) regenerated from three seeds w1 = W, w4 = W^4, wq = W^((K + 1) / 2) instead of being held in
+// 2 K registers: K - 3 complex products (four instructions each), none more than four (K = 15) or five
+// (K = 31) products deep, so a twiddle carries a handful of float32 roundings (tests/test_twiddle_chain.py
+// replays this routine against float64: max error 1.3e-7 / 2e-7 over all lanes of the 32 x 16 / 64 x 16
+// geometries).  t[(K + 1) / 2] comes out DOUBLED: the caller feeds rdft_scaled a window times 1/2, which makes
+// that routine's outputs A[k] for k != M/4 and A[M/4] / 2 (see rdft_scaled), so no twiddle needs a scale factor
+// of its own.
 PDS_HD void cmul(float ar, float ai, float br, float bi, float &cr, float &ci) {
   cr = fmaf(ar, br, -(ai * bi));
   ci = fmaf(ar, bi, ai * br);
 }
-PDS_HD void twiddle_chain15(float w1r, float w1i, float w4r, float w4i, float w8r, float w8i, float *tr, float *ti) {
+template <int K>
+PDS_HD void twiddle_chain(float w1r, float w1i, float w4r, float w4i, float wqr, float wqi, float *tr, float *ti) {
+  static_assert(K == 15 || K == 31, "twiddles of the 32- and 64-point in-lane transforms");
+  constexpr int Q = (K + 1) / 2;  // 8 or 16
   tr[1] = w1r, ti[1] = w1i;
   tr[4] = w4r, ti[4] = w4i;
   cmul(w1r, w1i, w1r, w1i, tr[2], ti[2]);
@@ -209,11 +213,21 @@ PDS_HD void twiddle_chain15(float w1r, float w1i, float w4r, float w4i, float w8
   cmul(w1r, w1i, w4r, w4i, tr[5], ti[5]);
   cmul(tr[2], ti[2], w4r, w4i, tr[6], ti[6]);
   cmul(tr[3], ti[3], w4r, w4i, tr[7], ti[7]);
-  tr[8] = w8r + w8r, ti[8] = w8i + w8i;
-  static_for<1, 8>([&](auto kk) {
+  if constexpr (K == 31) {
+    cmul(w4r, w4i, w4r, w4i, tr[8], ti[8]);
+    static_for<1, 8>([&](auto kk) {
+      constexpr int k = decltype(kk)::value;
+      cmul(tr[k], ti[k], tr[8], ti[8], tr[8 + k], ti[8 + k]);
+    });
+  }
+  static_for<1, Q>([&](auto kk) {
     constexpr int k = decltype(kk)::value;
-    cmul(tr[k], ti[k], w8r, w8i, tr[8 + k], ti[8 + k]);
+    cmul(tr[k], ti[k], wqr, wqi, tr[Q + k], ti[Q + k]);
   });
+  tr[Q] = wqr + wqr, ti[Q] = wqi + wqi;
+}
+PDS_HD void twiddle_chain15(float w1r, float w1i, float w4r, float w4i, float w8r, float w8i, float *tr, float *ti) {
+  twiddle_chain<15>(w1r, w1i, w4r, w4i, w8r, w8i, tr, ti);
 }
 
 // cos / -sin of 2 pi K / M for the mixed-radix sizes (M divides 600)

@@ -358,13 +358,15 @@ int32_t fast_tables_create(pds_stft_plan *plan, const double *window, const int3
   if (rc == PDS_OK) rc = upload(&ft.d_ell_woff, ell_woff.data(), ell_woff.size());
   if (rc == PDS_OK) rc = upload(&ft.d_window, win.data(), win.size());
   if (rc == PDS_OK) rc = upload(&ft.d_twiddle, tw.data(), tw.size());
-  if (PDS_EXPERIMENTS && n1 == 32 && n2 == 16) {
-    // prefetch instantiations: window times 1/2 and the twiddle seeds W_N^r, W_N^4r, W_N^8r (see twiddle_chain15)
+  if ((n1 == 32 || n1 == 64) && n2 == 16) {
+    // float64-sample instantiations (and the prefetch experiment): window times 1/2 and the twiddle seeds
+    // W_N^r, W_N^4r, W_N^(n1/4 r) (inl::twiddle_chain)
     std::vector<float> wh(win), seed((size_t)n2 * 6);
     for (float &v : wh) v *= 0.5f;
+    const int mult[3] = {1, 4, n1 / 4};
     for (int r = 0; r < n2; ++r)
       for (int j = 0; j < 3; ++j) {
-        const double ang = -2.0 * M_PI * (double)((r * (j == 0 ? 1 : 4 * j)) % N) / (double)N;
+        const double ang = -2.0 * M_PI * (double)((r * mult[j]) % N) / (double)N;
         seed[((size_t)r * 3 + j) * 2 + 0] = (float)std::cos(ang);
         seed[((size_t)r * 3 + j) * 2 + 1] = (float)std::sin(ang);
       }

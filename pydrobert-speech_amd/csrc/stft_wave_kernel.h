@@ -380,7 +380,11 @@ __global__ __launch_bounds__(MAXWAVES * 64, MINW) void stft_wave_kernel(const Fa
   float2 *sw_lds = reinterpret_cast<float2 *>(smem + p.waves * (G::EXCH_F2 * 2));  // [N2]
   int *meta_lds = reinterpret_cast<int *>(sw_lds + N2);
   float *ellw_lds = reinterpret_cast<float *>(meta_lds + p.ell_meta_pad);
-  constexpr bool TWCHAIN = PF && PDS_PF_TW == 1;  // twiddles regenerated per item; window times 1/2
+  // twiddles regenerated per item from three seeds (inl::twiddle_chain) and a window times 1/2: the float64-sample
+  // instantiations of the 16-lane geometries, whose 16-byte pair loads keep 4 registers per pair in flight (52 at 25
+  // rows: with thirty registers of twiddles beside them the kernel spilled 10 ... 34 registers), and the prefetch
+  // experiment
+  constexpr bool TWCHAIN = (PF && PDS_PF_TW == 1) || (PAIR && (N1 == 32 || N1 == 64));
   constexpr bool WINLDS = PF && PDS_PF_WIN == 1;  // window slice re-read from LDS per item
   constexpr int WSTR = ((NROWS + 3) & ~3) % 8 == 4 ? ((NROWS + 3) & ~3) : ((NROWS + 3) & ~3) + 4;  // row stride = 4 (mod 8) floats: conflict-free 16-byte reads
   [[maybe_unused]] float *win_lds = ellw_lds + (ELL_LDS ? p.ell_wfloats : 0);  // [N2][WSTR]
@@ -994,19 +998,33 @@ __global__ __launch_bounds__(MAXWAVES * 64, MINW) void stft_wave_kernel(const Fa
           // does not move loads across -- interleaved in the source, every load waited for the one before)
           constexpr int NP = (NROWS + 1) / 2;
           D2 w2[NP];
-          [[maybe_unused]] double wprev[PRE ? NP : 1];
+          // PRE: the sample in front of a lane's pair is the second sample of the lane before (row_shr:1; lane 8's
+          // is lane 7's: the end of the even row), and lane 0's the second sample of lane 15's PREVIOUS pair (the
+          // end of the odd row before: row_ror:1 of that pair, kept as `old` where row_shr has no source lane) --
+          // no second load per pair (round 2 loaded the predecessors: 13 more 8-byte loads on the unit this
+          // kernel is bound by, and 26 more registers in flight: 34 spilled).  Only the sample in front of the
+          // frame is loaded, by lane 0.
+          [[maybe_unused]] double before = 0.0;
 #pragma unroll
-          for (int j = 0; j < NP; ++j) {
-            w2[j] = *reinterpret_cast<const D2 *>(xq + 32 * j);
-            if constexpr (PRE) wprev[j] = xq[32 * j - 1];
+          for (int j = 0; j < NP; ++j) w2[j] = *reinterpret_cast<const D2 *>(xq + 32 * j);
+          if constexpr (PRE) {
+            if (r == 0) before = xq[-1];
           }
+          [[maybe_unused]] auto dpp64 = [](double old, double src, auto ctrl) {
+            const long long o = __double_as_longlong(old), s_ = __double_as_longlong(src);
+            const int lo = __builtin_amdgcn_update_dpp((int)o, (int)s_, decltype(ctrl)::value, 0xf, 0xf, false);
+            const int hi = __builtin_amdgcn_update_dpp((int)(o >> 32), (int)(s_ >> 32), decltype(ctrl)::value, 0xf, 0xf, false);
+            return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
+          };
 #pragma unroll
           for (int j = 0; j < NP; ++j) {
             double u = w2[j].x, v = w2[j].y;
             if constexpr (PRE) {
               // float64 pre-emphasis before the rounding (pre.py:140-149): v's predecessor is u
+              const double wrap = j == 0 ? before : dpp64(0.0, (double)w2[j > 0 ? j - 1 : 0].y, inl::Int<0x121>{});  // row_ror:1
+              const double pu = dpp64(wrap, (double)w2[j].y, inl::Int<0x111>{});                                 // row_shr:1
               v = preemph_sample(w2[j].y, w2[j].x, (TIN)p.preemph_d);
-              u = preemph_sample(w2[j].x, wprev[j], (TIN)p.preemph_d);
+              u = preemph_sample(w2[j].x, pu, (TIN)p.preemph_d);
             }
             const float fu = (float)u, fv = (float)v;
             // lanes 8..15 take residue 2s + 1 of the even row from lane s; lanes 0..7 take residue 2s of
@@ -1130,7 +1148,13 @@ __global__ __launch_bounds__(MAXWAVES * 64, MINW) void stft_wave_kernel(const Fa
         row0[N2 + rho] = odd_sum;
       }
       [[maybe_unused]] float ctr[TWCHAIN ? COLS : 1], cti[TWCHAIN ? COLS : 1];
-      if constexpr (TWCHAIN) inl::twiddle_chain15(sd[0], sd[1], sd[2], sd[3], sd[4], sd[5], ctr, cti);
+      if constexpr (TWCHAIN) {
+        // (the seeds pass through an opaque asm: the chain is loop invariant, and hoisted out of the item loop it
+        // would sit in the thirty registers it is there to free)
+#pragma unroll
+        for (int j = 0; j < 6; ++j) asm volatile("" : "+v"(sd[j]));
+        inl::twiddle_chain<NREG>(sd[0], sd[1], sd[2], sd[3], sd[4], sd[5], ctr, cti);
+      }
 #pragma unroll
       for (int k1 = 1; k1 <= NREG; ++k1) {
         const float wr_ = TWCHAIN ? ctr[TWCHAIN ? k1 : 0] : twr[TWCHAIN ? 0 : k1];
@@ -2054,6 +2078,8 @@ int32_t launch_wave(const pds_stft_plan *plan, const BatchArgs &a) {
         return PDS_ERR_INVALID;
       }
       mf = false;
+      p.win_half = ft.d_win_half;  // (16-lane geometries: twiddles regenerated from seeds, see the kernel)
+      p.tw_seed = (const float2 *)ft.d_tw_seed;
       if (a.out_f64)
         kern = rsg ? stft_wave_kernel<N1, N2, NROWS, CU_WAVES_K, MINW, true, false, false, 0, W4, double, double>
                    : stft_wave_kernel<N1, N2, NROWS, CU_WAVES_K, MINW, true, false, false, 0, false, double, double>;
