@@ -226,7 +226,7 @@ int32_t fast_tables_create(pds_stft_plan *plan, const double *window, const int3
     long ell_reads = 0;
     for (int sl = 0; sl < slots; ++sl) ell_reads += 2L * (ell_len[sl] / 4);  // per lane and item
     ft.ell_reads = ell_reads;
-    const int free_slots = (groups * cols * (n2 + 2) * 2 - groups * pstr) / groups;  // partial slots behind P
+    const int free_slots = (wave_area_floats(n1, n2) - groups * pstr) / groups;  // partial slots behind P
     int best_len = 0, best_rounds = 0;
     long best_reads = 0;
     const char *only_len = std::getenv("PDS_SEG_LEN");  // (measurement: one segment length)
@@ -290,7 +290,7 @@ int32_t fast_tables_create(pds_stft_plan *plan, const double *window, const int3
   // of the walks (measurement); by default the one with the fewest 16-byte LDS reads per item runs.
   if (n2 == 16 && rc == PDS_OK) {
     RsegTables rs;
-    const int area_floats = 4 * cols * (n2 + 2) * 2;  // WaveGeom::EXCH_F2 * 2
+    const int area_floats = wave_area_floats(n1, n2);  // WaveGeom::EXCH_F2 * 2
     if (build_rseg(d.num_filts, row_ptr, col, val, N / 2 + 1, area_floats / 4, 8, rs)) {
       ft.rs_rounds = rs.rounds;
       ft.rs_len = rs.seg_len;
@@ -318,7 +318,7 @@ int32_t fast_tables_create(pds_stft_plan *plan, const double *window, const int3
   // power-of-two 16-lane geometries
   if (n2 == 16 && pow2 && rc == PDS_OK && ft.seg_rounds > 0) {
     MsegTables ms;
-    const int area_floats = 4 * cols * (n2 + 2) * 2;  // WaveGeom::EXCH_F2 * 2
+    const int area_floats = wave_area_floats(n1, n2);  // WaveGeom::EXCH_F2 * 2
     const int max_units = (area_floats - 4 * pstr) / 16;  // four float4 partial slots per unit behind P
     if (build_mseg(d.num_filts, row_ptr, col, val, pstr, max_units, ms)) {
       ft.ms_rounds = ms.rounds;

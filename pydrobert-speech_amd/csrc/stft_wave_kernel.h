@@ -259,6 +259,21 @@ __device__ __forceinline__ void wave_sync() {
 // N1 is a power of two (N = 128 .. 2048, radix-2 network) or, for transforms without zero
 // padding (pad_to_nearest_power_of_two = False: N = L = 160, 200, 240, 320, 400, 480, 640, 800,
 // 960), one of 20, 25, 30 evaluated directly; N2 is always a power of two.
+// Two-pass exchange (the 64 x 16 geometry, N = 1024): a lane owns two columns there, and the exchange of all
+// 32 columns at once takes 18.4 KB of LDS per wave -- beside the 38 KB filter table of the 64 gammatone filters at
+// 48 kHz (BASELINE.json configs[4]) six waves per CU.  Columns 0..15 and 16..31 go through the SAME 16 rows one after
+// the other instead (the second half waits, twiddled, in 32 registers: the geometry is built for two waves per SIMD
+// and has them), so a wave's area is what the power spectra and the filter walk's partial sums need, 13.5 KB, and
+// eight waves fit.  -DPDS_TWOPASS=0: the one-pass exchange of rounds 1-2 (A/B builds).
+#ifndef PDS_TWOPASS
+#define PDS_TWOPASS 1
+#endif
+// floats of a wave's private LDS area (exchange, then power spectra + the walks' partial sums)
+constexpr int wave_area_floats(int n1, int n2) {
+  const int cols = (n1 - 1) / 2 + 1, groups = 64 / n2, one_pass = groups * cols * (n2 + 2) * 2;
+  return (PDS_TWOPASS && n1 == 64 && n2 == 16) ? 3456 : one_pass;
+}
+
 template <int N1, int N2, int NROWS>
 struct WaveGeom {
   static constexpr int N = N1 * N2;
@@ -271,12 +286,15 @@ struct WaveGeom {
   static constexpr int GROUPS = 64 / N2;    // frames per wave iteration
   static constexpr int NB = N / 2 + 1;      // half-spectrum bins
   static constexpr int RS = N2 + 2;         // exchange row stride (float2): conflict-free
-  static constexpr int EXCH_F2 = GROUPS * COLS * RS;  // float2 per wave
+  static constexpr bool TWOPASS = PDS_TWOPASS && N1 == 64 && N2 == 16;
+  static constexpr int XROWS = TWOPASS ? N2 : COLS;      // rows of a frame's exchange block
+  static constexpr int EXCH_F2 = wave_area_floats(N1, N2) / 2;  // float2 per wave (the wave's whole area)
+  static_assert(GROUPS * XROWS * RS <= EXCH_F2, "the exchange must fit the wave's area");
   // P row stride: >= NB + 1 (energy) and = 16 (mod 32) so that the two frames sharing a
   // 32-lane half write to disjoint banks
   static constexpr int PSTR = ((NB + 1 + 15) / 32) * 32 + 16;
   static_assert(GROUPS * PSTR <= EXCH_F2 * 2, "P must fit over the exchange area");
-  static_assert(EXCH_F2 * 2 >= 64 * NROWS, "edge-frame gather reuses the exchange area");
+  static constexpr int GCH = EXCH_F2 * 2 / 64 < NROWS ? EXCH_F2 * 2 / 64 : NROWS;  // rows per pass of the edge-frame gather
   static_assert(N % 2 == 0 && CPL >= 1 && N2 <= 64 && (RS * 8) % 16 == 0, "geometry");
   // (N = 4096 = 64 x 64 has 32 columns for 64 lanes: the upper half of the wave idles in step 3)
   static_assert(inl::is_pow2(N1) ? (FULL || N2 == 2 * COLS) : 600 % N1 == 0,
@@ -371,7 +389,7 @@ __global__ __launch_bounds__(MAXWAVES * 64, MINW) void stft_wave_kernel(const Fa
   constexpr int LOADSPAN = PAIR ? (NROWS + 1) / 2 * 32 : NROWS * N2;  // samples a frame's direct loads reach over
   [[maybe_unused]] const unsigned long long st_entry = PDS_STAMPS ? __builtin_readcyclecounter() : 0;
   float *wbase = smem + wave * (G::EXCH_F2 * 2);
-  float2 *exch = reinterpret_cast<float2 *>(wbase) + g * COLS * RS;
+  float2 *exch = reinterpret_cast<float2 *>(wbase) + g * G::XROWS * RS;
   float *Pg = wbase + g * PSTR;
   // filter table -> LDS once per workgroup (read by every wave, every iteration): per-slot
   // weight rows.  Tables too large for LDS (dense complex banks) stay in global memory and
@@ -1067,33 +1085,38 @@ __global__ __launch_bounds__(MAXWAVES * 64, MINW) void stft_wave_kernel(const Fa
           }
         }
       } else {
+        // (rolled: the lane writes and reads back its own slots, GCH rows per pass through the wave's area)
         float *tmp = wbase;
+        inl::static_for<0, (NROWS + G::GCH - 1) / G::GCH>([&](auto cc) {
+          constexpr int base = decltype(cc)::value * G::GCH;
+          constexpr int top = base + G::GCH < NROWS ? base + G::GCH : NROWS;
 #pragma unroll 1
-        for (int n1 = 0; n1 < NROWS; ++n1) {
-          const int idx = n1 * N2 + rho;
-          float v = 0.0f;
-          if (idx < L) {
-            int i = start + idx;
-            if (wmode == 1) {
-              i = i < 0 ? -1 - i : (i >= n ? 2 * n - 1 - i : i);
-            } else {
-              i = (int)reflect_index((int64_t)i, (int64_t)n);
+          for (int n1 = base; n1 < top; ++n1) {
+            const int idx = n1 * N2 + rho;
+            float v = 0.0f;
+            if (idx < L) {
+              int i = start + idx;
+              if (wmode == 1) {
+                i = i < 0 ? -1 - i : (i >= n ? 2 * n - 1 - i : i);
+              } else {
+                i = (int)reflect_index((int64_t)i, (int64_t)n);
+              }
+              if constexpr (std::is_same<TIN, float>::value) {
+                v = (float)x[i];
+                if (PRE && i > 0) v = preemph_sample(v, (float)x[i - 1], p.preemph);
+              } else {
+                TIN w = x[i];
+                if (PRE && i > 0) w = preemph_sample(w, x[i - 1], (TIN)p.preemph_d);
+                v = (float)w;
+              }
             }
-            if constexpr (std::is_same<TIN, float>::value) {
-              v = (float)x[i];
-              if (PRE && i > 0) v = preemph_sample(v, (float)x[i - 1], p.preemph);
-            } else {
-              TIN w = x[i];
-              if (PRE && i > 0) w = preemph_sample(w, x[i - 1], (TIN)p.preemph_d);
-              v = (float)w;
-            }
+            tmp[(n1 - base) * 64 + lane] = v;
           }
-          tmp[n1 * 64 + lane] = v;
-        }
-        wave_sync();
+          wave_sync();
 #pragma unroll
-        for (int n1 = 0; n1 < NROWS; ++n1) a[n1] = tmp[n1 * 64 + lane];
-        wave_sync();
+          for (int n1 = base; n1 < top; ++n1) a[n1] = tmp[(n1 - base) * 64 + lane];
+          wave_sync();
+        });
       }
       if (p.include_energy) {
         // compute.py:392-393, on the un-windowed samples of the frame proper
@@ -1162,7 +1185,11 @@ __global__ __launch_bounds__(MAXWAVES * 64, MINW) void stft_wave_kernel(const Fa
         float2 v;
         v.x = Ar[k1] * wr_ - Ai[k1] * wi_;
         v.y = Ar[k1] * wi_ + Ai[k1] * wr_;
-        if constexpr (PDS_ABLATE & 4) {
+        if constexpr ((PDS_ABLATE & 4) != 0) {
+          Ar[k1] = v.x;
+          Ai[k1] = v.y;
+        } else if (G::TWOPASS && k1 >= N2) {
+          // two-pass exchange: the second half of the columns waits, twiddled, for the first half's transforms
           Ar[k1] = v.x;
           Ai[k1] = v.y;
         } else {
@@ -1250,7 +1277,16 @@ __global__ __launch_bounds__(MAXWAVES * 64, MINW) void stft_wave_kernel(const Fa
 #pragma unroll
     for (int q = 0; q < G::CPL; ++q) {
       const int kk = q * N2 + r;
-      const float4 *row = reinterpret_cast<const float4 *>(exch + kk * RS);
+      if constexpr (G::TWOPASS) {
+        if (q > 0) {
+          // (every lane has read its column of the pass before: same wave, in order)
+          wave_sync();
+#pragma unroll
+          for (int k1 = q * N2; k1 < (q + 1) * N2 && k1 <= NREG; ++k1) exch[(k1 - q * N2) * RS + rho] = make_float2(Ar[k1], Ai[k1]);
+          wave_sync();
+        }
+      }
+      const float4 *row = reinterpret_cast<const float4 *>(exch + (G::TWOPASS ? r : kk) * RS);
       float zr[N2], zi[N2], Yr[N2], Yi[N2];
 #pragma unroll
       for (int j = 0; j < N2 / 2; ++j) {
