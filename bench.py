@@ -225,11 +225,16 @@ def parity_spot_check(comp, signal, offsets, lengths, layout, out, picks=3, num_
             derr = np.abs(mine[:, C:].astype(np.float64) - ref[:, C:])
             if np.isnan(derr).any():
                 return {"pass": False, "error": f"utterance {b}: NaN in the deltas"}
-            worst_delta = max(worst_delta, float((derr / (1e-5 + 1e-4 * np.abs(want).max())).max()))
+            # (bounded as tests/test_gpu_post.py bounds them: 4e-6 of the statics' scale -- float32 accumulation
+            # against float64 -- not by the feature tolerance, which at statics of ~20 would be 500 x looser)
+            worst_delta = max(worst_delta, float((derr / (4e-6 * max(float(np.abs(want).max()), 1.0))).max()))
     res_d = {"deltas_max_err_over_tolerance": worst_delta, "deltas_columns": num_deltas * C} if num_deltas else {}
-    return {"pass": worst_tol <= 1.0 and worst_delta <= 1.0, "utterances": utts, "rows": rows, "coeffs": C,
+    # (a line whose statics pass only through the float32-floor rule in more than 0.1 % of the elements fails;
+    # pre-emphasised white noise leaves ~0.02 % of them there: the lowest filters of a few frames)
+    return {"pass": worst_tol <= 1.0 and worst_delta <= 1.0 and floor_elems <= max(4, rows * C // 1000),
+            "utterances": utts, "rows": rows, "coeffs": C,
             "max_abs_err": worst_abs, "max_err_over_tolerance": worst_tol, "tolerance": "1e-5 + 1e-4 |ref|",
-            "elements_at_the_float32_floor": floor_elems, **res_d,
+            "elements_at_the_float32_floor": floor_elems, "deltas_tolerance": "4e-6 max(|statics|, 1)", **res_d,
             "against": "oracle/stft_oracle.compute_full (float64) on the timed buffer's own input"}
 
 
@@ -369,17 +374,19 @@ def main():
     cmvn_out = None
 
     fused_deltas_used = bool(
-        deltas is not None and not args.two_launch_deltas and not args.generic and args.dtype == "f32"
-        and not args.preemph and not is_si and comp._native_plan(dev).has_fused_deltas)
+        deltas is not None and not args.two_launch_deltas and not args.generic
+        and not is_si and comp._native_plan(dev).has_fused_deltas)
 
     def step():
         nonlocal cmvn_out
         if is_si:
             comp.compute_packed(signal, offsets, lengths, out=out, direct=args.generic)
             return
-        if deltas is not None and not args.two_launch_deltas and not args.generic and args.dtype == "f32" and not args.preemph:
-            # statics and deltas by one launch where the plan has it (pds_stft_deltas_batch_f32), else the two
-            comp.launch_with_deltas(signal, layout, deltas, out=out_wide if out_wide is not None else out, fused=True)
+        if deltas is not None and not args.two_launch_deltas and not args.generic:
+            # statics and deltas by one launch where the plan has it (pds_stft_deltas_batch: float32 or float64
+            # samples, fused pre-emphasis), else the two
+            comp.launch_with_deltas(signal, layout, deltas, out=out_wide if out_wide is not None else out, fused=True,
+                                    preemphasis=args.preemph)
             return
         comp.launch(signal, layout, out=out, generic=args.generic, preemphasis=args.preemph)
         if deltas is not None:  # statics were written with row stride 3C; deltas go beside them
@@ -539,7 +546,7 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32",
+            "dtype": "f64in->f32" if args.dtype == "f64in" else "f32",  # (samples in HBM -> arithmetic and features)
             "data": "synthetic",
             "config": {
                 "workload": args.workload + ("+ragged_1to15s" if args.ragged else "")
@@ -552,7 +559,7 @@ def main():
                 "kernel": ("si-direct-fir" if (args.generic or not comp.fft_size) else
                            f"si-overlap-save-fft{comp.fft_size}") if is_si else
                           "generic (lds-fft for 2^k sizes, else direct-dft)" if (args.generic or not comp.kernel_kind) else "fused-fft",
-                **({"deltas": "same launch (pds_stft_deltas_batch_f32)" if fused_deltas_used else "second launch (pds_deltas_rows_f32)"}
+                **({"deltas": "same launch (pds_stft_deltas_batch)" if fused_deltas_used else "second launch (pds_deltas_rows_f32)"}
                    if deltas is not None else {}),
             },
             "roofline": {

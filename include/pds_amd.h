@@ -163,8 +163,21 @@ int32_t pds_stft_batch_ragged_f32(const pds_stft_plan *plan, const float *d_sign
  * deltas are formed in float32 where pds_deltas_rows_f32 (and the reference) accumulate in float64
  * and round: they agree within a few float32 ulps of the statics, i.e. inside the feature tolerance.
  * Served for plans with transform sizes 512 and 1024 whose banks run the row-segment filter walk in
- * at most two rounds (mel banks of up to ~100 filters): pds_stft_plan_has_fused_deltas(). */
+ * at most two rounds (mel banks of up to ~100 filters): pds_stft_plan_has_fused_deltas().  (The statics are
+ * bit-identical to pds_stft_batch_f32's when that launch takes the row-segment walk too; a plan that prefers
+ * another walk for the plain launch sums the same products in another order: a few float32 ulps.) */
 int32_t pds_stft_plan_has_fused_deltas(const pds_stft_plan *plan);
+/* ... with everything the reference's drivers put in front of compute_full (command_line.py:345-350): `d_signal`
+ * float32 (signal_is_f64 = 0) or float64 samples (1: plans with pds_stft_plan_has_f64in(); rounded to float32 as the
+ * frame is loaded, as in pds_stft_batch_f64in) and a fused pre-emphasis (`preemph` != 0, pre.py:140-149: in the
+ * signal's own precision, before the rounding).  float64 audio -> Preemphasize -> compute_full -> Deltas in one
+ * launch; features float32. */
+int32_t pds_stft_deltas_batch(const pds_stft_plan *plan, const void *d_signal, int32_t signal_is_f64,
+                              const int64_t *d_offsets, const int64_t *d_lengths, const int64_t *d_nframes,
+                              const int64_t *d_row_off, int32_t B, int64_t max_frames, int32_t pad_left,
+                              double preemph, int32_t num_deltas, int32_t context_window, const double *taps,
+                              int64_t *d_workspace, float *d_out, int64_t out_stride, void *stream);
+/* (float32 samples, no pre-emphasis: the round-2 signature) */
 int32_t pds_stft_deltas_batch_f32(const pds_stft_plan *plan, const float *d_signal,
                                   const int64_t *d_offsets, const int64_t *d_lengths,
                                   const int64_t *d_nframes, const int64_t *d_row_off, int32_t B,

@@ -172,10 +172,9 @@ class PackedLayout:
         self.row_offsets = row_offsets  # host int64[B + 1]
         self.d_meta = d_meta  # device int64[4, B]: offsets, lengths, nframes, row offsets
         # share of the (utterance, frame < longest) grid that exists: ragged batches (< 0.9) take the launch
-        # that deals the existing chunks evenly (pds_stft_batch_ragged_f32); its device workspace, on demand
+        # that deals the existing chunks evenly (pds_stft_batch_ragged_f32)
         top = int(nframes.max()) if B else 0
         self.fill = float(nframes.sum()) / (top * B) if top else 1.0
-        self.d_work = None
 
     @property
     def total_rows(self) -> int:
@@ -459,10 +458,10 @@ class ShortTimeFourierTransformFrameComputer(LinearFilterBankFrameComputer):
         elif signal.dtype == torch.float32:
             fn = lib.pds_stft_batch_f32_generic if generic else lib.pds_stft_batch_f32
             if not generic and not preemphasis and plan.kernel_kind and layout.fill < 0.9 and config.RAGGED_SCHEDULING:
-                if layout.d_work is None or layout.d_work.device != signal.device:
-                    layout.d_work = torch.empty(min(layout.B, _MAX_UTTS_PER_CALL) + 1, dtype=torch.int64,
-                                                device=signal.device)
-                work = layout.d_work.data_ptr()
+                # (per launch, from the caching allocator: a workspace kept on the layout was shared by launches on
+                # different streams, and chunk_prefix_kernel rewrites it every time)
+                d_work = torch.empty(min(layout.B, _MAX_UTTS_PER_CALL) + 1, dtype=torch.int64, device=signal.device)
+                work = d_work.data_ptr()
 
                 def fn(*args):
                     return lib.pds_stft_batch_ragged_f32(*args[:10], work, *args[10:])
@@ -510,7 +509,7 @@ class ShortTimeFourierTransformFrameComputer(LinearFilterBankFrameComputer):
         return out
 
     def launch_with_deltas(self, signal, layout: "PackedLayout", deltas, out=None, pad_left=None,
-                           fused: Optional[bool] = None):
+                           fused: Optional[bool] = None, preemphasis: float = 0.0):
         """Statics and ``deltas`` (a :class:`pydrobert_speech_amd.post.Deltas`) of a packed batch
 
         Returns the ``(total_rows, (K + 1) num_coeffs)`` float32 tensor: row r holds the features of
@@ -523,6 +522,12 @@ class ShortTimeFourierTransformFrameComputer(LinearFilterBankFrameComputer):
         when ``fused`` is left at ``None`` and the plan has it (1.34 x the rate of the two launches on
         BASELINE.json configs[2]); ``fused=False`` keeps the two launches, whose deltas are numpy's bit
         for bit.
+
+        `preemphasis` as in :func:`launch`; float64 signals take the one launch too when
+        ``config.FLOAT64_ARITHMETIC == "float32"`` (samples rounded as the frame is loaded, after the
+        pre-emphasis: ``pds_stft_deltas_batch``) -- the reference drivers' chain float64 audio ->
+        Preemphasize -> compute_full -> Deltas (command_line.py:345-350) as one kernel.  Otherwise their
+        statics are computed in float64 (:func:`launch`) and rounded into the float32 result.
         """
         if fused is None:
             fused = True
@@ -537,8 +542,11 @@ class ShortTimeFourierTransformFrameComputer(LinearFilterBankFrameComputer):
             raise ValueError("out has the wrong dtype, shape or strides")
         plan = self._native_plan(signal.device)
         filts = deltas._filts[1:]
+        f64in = signal.dtype == torch.float64 and config.FLOAT64_ARITHMETIC == "float32" and plan.has_f64in
+        if signal.dtype not in (torch.float32, torch.float64):
+            raise TypeError("signal must be float32 or float64")
         fused = (
-            fused and plan.has_fused_deltas and signal.dtype == torch.float32 and K in (1, 2) and deltas.concatenate
+            fused and plan.has_fused_deltas and (signal.dtype == torch.float32 or f64in) and K in (1, 2) and deltas.concatenate
             and deltas._pad_mode == "edge" and not deltas._pad_kwargs
             and [len(f) for f in filts] == [5, 9][:K] and total > 0
         )
@@ -555,17 +563,22 @@ class ShortTimeFourierTransformFrameComputer(LinearFilterBankFrameComputer):
                 work = torch.empty(min(layout.B, _MAX_UTTS_PER_CALL) + 1, dtype=torch.int64, device=signal.device)
                 for lo in range(0, layout.B, _MAX_UTTS_PER_CALL):
                     hi = min(layout.B, lo + _MAX_UTTS_PER_CALL)
-                    rc = lib.pds_stft_deltas_batch_f32(
-                        plan.handle, signal.data_ptr(), meta[0, lo:].data_ptr(), meta[1, lo:].data_ptr(),
-                        meta[2, lo:].data_ptr(), meta[3, lo:].data_ptr(), hi - lo, int(layout.nframes[lo:hi].max()),
-                        pad, K, 2, taps.ctypes.data, work.data_ptr(), out.data_ptr(), out.stride(0), stream,
+                    rc = lib.pds_stft_deltas_batch(
+                        plan.handle, signal.data_ptr(), int(signal.dtype == torch.float64), meta[0, lo:].data_ptr(),
+                        meta[1, lo:].data_ptr(), meta[2, lo:].data_ptr(), meta[3, lo:].data_ptr(), hi - lo,
+                        int(layout.nframes[lo:hi].max()), pad, float(preemphasis), K, 2, taps.ctypes.data,
+                        work.data_ptr(), out.data_ptr(), out.stride(0), stream,
                     )
                     if rc != 0 and lo == 0:
                         fused = False  # (e.g. a filter table that does not fit in LDS): the two launches below
                         break
                     _native.check(rc, "pds_stft_deltas_batch")
         if not fused:
-            self.launch(signal, layout, out=out, pad_left=pad_left)
+            if signal.dtype == torch.float32 or f64in:
+                self.launch(signal, layout, out=out, pad_left=pad_left, preemphasis=preemphasis)
+            elif total:
+                # float64 arithmetic (config.FLOAT64_ARITHMETIC == "float64"): float64 statics, rounded into the rows
+                out[:total, :C] = self.launch(signal, layout, pad_left=pad_left, preemphasis=preemphasis)
             if total:
                 deltas.apply_rows(out[:, :C], layout.row_offsets, out=out)
         return out[:, : (K + 1) * C] if out.shape[1] != (K + 1) * C else out

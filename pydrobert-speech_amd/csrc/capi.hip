@@ -226,16 +226,18 @@ int32_t pds_stft_batch_ragged_f32(const pds_stft_plan *plan, const float *d_sign
   return plan->fast.kind ? pds::launch_stft_fast_f32(plan, a) : pds::launch_stft_generic_f32(plan, a);
 }
 
-int32_t pds_stft_deltas_batch_f32(const pds_stft_plan *plan, const float *d_signal, const int64_t *d_offsets,
-                                  const int64_t *d_lengths, const int64_t *d_nframes, const int64_t *d_row_off,
-                                  int32_t B, int64_t max_frames, int32_t pad_left, int32_t num_deltas,
-                                  int32_t context_window, const double *taps, int64_t *d_workspace, float *d_out,
-                                  int64_t out_stride, void *stream) {
+int32_t pds_stft_deltas_batch(const pds_stft_plan *plan, const void *d_signal, int32_t signal_is_f64,
+                              const int64_t *d_offsets, const int64_t *d_lengths, const int64_t *d_nframes,
+                              const int64_t *d_row_off, int32_t B, int64_t max_frames, int32_t pad_left, double preemph,
+                              int32_t num_deltas, int32_t context_window, const double *taps, int64_t *d_workspace,
+                              float *d_out, int64_t out_stride, void *stream) {
   int32_t rc = check_batch(plan, d_signal, d_offsets, d_lengths, d_nframes, d_row_off, B, max_frames, pad_left,
                            d_out, out_stride);
   if (rc == 1) return PDS_OK;
   if (rc != PDS_OK) return rc;
   if (!pds::fast_has_fused_deltas(plan)) return invalid("stft_deltas_batch: the plan has no fused statics + deltas kernel");
+  if (signal_is_f64 && !pds::fast_has_f64in(plan))
+    return invalid("stft_deltas_batch: float64 samples are not served for this plan (pds_stft_plan_has_f64in)");
   if (num_deltas < 1 || num_deltas > 2 || context_window != 2 || !taps)
     return invalid("stft_deltas_batch: orders 1 and 2 with context_window 2 only (and their taps)");
   if (!d_workspace) return invalid("stft_deltas_batch: null workspace (B + 1 int64 on the device)");
@@ -244,11 +246,21 @@ int32_t pds_stft_deltas_batch_f32(const pds_stft_plan *plan, const float *d_sign
   rc = pds::check_plan_device(plan->device, "stft_batch");
   if (rc != PDS_OK) return rc;
   pds::BatchArgs a{d_signal,   d_offsets, d_lengths,  d_nframes, d_row_off, B, max_frames,
-                   pad_left < 0 ? plan->d.pad_left : pad_left, 0.0, d_out, out_stride, (hipStream_t)stream};
+                   pad_left < 0 ? plan->d.pad_left : pad_left, preemph, d_out, out_stride, (hipStream_t)stream};
+  a.in_f64 = signal_is_f64 != 0;
   a.dl_K = num_deltas;
   a.d_chunk_prefix = d_workspace;
   for (int j = 0; j < (num_deltas == 1 ? 5 : 14); ++j) a.dl_taps[j] = taps[j];
   return pds::launch_stft_fast_f32(plan, a);
+}
+
+int32_t pds_stft_deltas_batch_f32(const pds_stft_plan *plan, const float *d_signal, const int64_t *d_offsets,
+                                  const int64_t *d_lengths, const int64_t *d_nframes, const int64_t *d_row_off,
+                                  int32_t B, int64_t max_frames, int32_t pad_left, int32_t num_deltas,
+                                  int32_t context_window, const double *taps, int64_t *d_workspace, float *d_out,
+                                  int64_t out_stride, void *stream) {
+  return pds_stft_deltas_batch(plan, d_signal, 0, d_offsets, d_lengths, d_nframes, d_row_off, B, max_frames, pad_left,
+                               0.0, num_deltas, context_window, taps, d_workspace, d_out, out_stride, stream);
 }
 
 }  // extern "C"

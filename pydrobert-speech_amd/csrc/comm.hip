@@ -108,7 +108,13 @@ int32_t pds_comm_init_rank(const void *id128, int32_t world, int32_t rank, pds_c
   if (!lib) return PDS_ERR_INVALID;
   return no_throw("comm_init_rank", [&]() -> int32_t {
     auto comm = new pds_comm();
-    PDS_HIP(hipGetDevice(&comm->device));
+    {
+      const hipError_t err = hipGetDevice(&comm->device);
+      if (err != hipSuccess) {
+        delete comm;
+        return pds::hip_fail(err, "hipGetDevice");
+      }
+    }
     ncclUniqueId id;
     std::memcpy(&id, id128, sizeof id);
     const ncclResult_t res = lib->CommInitRank(&comm->comm, world, id, rank);

@@ -202,6 +202,7 @@ struct FastParams {
   // batch's chunks and keeps the statics of the last three chunks in registers (see the kernel)
   const int64_t *chunk_prefix;  // [num_utts + 1] chunks in front of every utterance (chunk_prefix_kernel)
   int dl_inner;                 // coefficients per frame (= num_coeffs): order k goes to columns [k C, (k + 1) C)
+  int dl_order;                 // 1 or 2: orders of deltas appended (the DLT instantiation serves both)
   int dl_debug;                 // measurement switches (PDS_DL_DEBUG): 1 no delta stores, 2 no deltas at all, 4 no statics stores
   int dl_eslot;                 // round * 64 + lane of a lane without a filter: carries the energy (-1: none)
   float dl_f1[5], dl_f2[9];     // taps of order 1 and order 2 (context window 2), correlation order
@@ -361,9 +362,12 @@ __global__ __launch_bounds__(MAXWAVES * 64, MINW) void stft_wave_kernel(const Fa
   // three waves per SIMD instead of four (the window registers) and ~14 multiply-adds per delta.  The
   // energy column has no filter lane: a spare lane of the walk (dl_eslot) collects the four frames'
   // energies and differentiates them like a filter.
-  static_assert(DLT == 0 || (DLT <= 2 && N2 == 16 && RSG && !PRE && std::is_same<TOUT, float>::value &&
-                             std::is_same<TIN, float>::value && MF == 0),
-                "fused deltas: order 1 or 2, row-segment walk, float32 samples and features");
+  // (DLT is 0 or 2: a launch with Deltas(1) runs the order-2 instantiation with p.dl_order = 1 -- the window
+  // registers are the same, and every template axis multiplies the instantiation matrix.  Round 3: fused
+  // pre-emphasis and float64 samples too -- the reference drivers' chain float64 audio -> Preemphasize ->
+  // compute_full -> Deltas, command_line.py:345-350, in one launch.)
+  static_assert(DLT == 0 || (DLT == 2 && N2 == 16 && RSG && std::is_same<TOUT, float>::value && MF == 0),
+                "fused deltas: row-segment walk, float32 features");
   static_assert(MF == 0 || std::is_same<TIN, float>::value, "matrix-pipe front end: float32 samples");
   using G = WaveGeom<N1, N2, NROWS>;
   constexpr int N = G::N, COLS = G::COLS, NREG = G::NREG, RS = G::RS, NB = G::NB, PSTR = G::PSTR;
@@ -642,7 +646,7 @@ __global__ __launch_bounds__(MAXWAVES * 64, MINW) void stft_wave_kernel(const Fa
   [[maybe_unused]] auto emit_rows = [&](const int ce, const float (&nx)[DR][4]) {
     if (p.dl_debug & 2) return;
     const int C = p.dl_inner;
-    const int W = (DLT + 1) * C, WS = (W + 3) & ~3;  // row width, staged row stride (floats)
+    const int W = (p.dl_order + 1) * C, WS = (W + 3) & ~3;  // row width, staged row stride (floats)
     float *stage = wbase;
     wave_sync();  // (the filter walk's reads of the area are done: same wave, in order)
 #pragma unroll
@@ -662,7 +666,7 @@ __global__ __launch_bounds__(MAXWAVES * 64, MINW) void stft_wave_kernel(const Fa
         for (int t = 1; t < 5; ++t) d = fmaf(p.dl_f1[t], v[q + 2 + t], d);
         mine[q * wrow] = v[4 + q];
         mine[q * wrow + wk] = d;
-        if constexpr (DLT == 2) {
+        if (p.dl_order == 2) {
           float dd = p.dl_f2[0] * v[q];
 #pragma unroll
           for (int t = 1; t < 9; ++t) dd = fmaf(p.dl_f2[t], v[q + t], dd);
@@ -2138,22 +2142,36 @@ int32_t launch_wave(const pds_stft_plan *plan, const BatchArgs &a) {
     constexpr bool DELTAS = fast_deltas_kind(N1 * N2) && G::GROUPS == 4;
     if constexpr (DELTAS) {
       const int staged = ((a.dl_K + 1) * (plan->d.num_filts + (plan->d.include_energy ? 1 : 0)) + 3) / 4 * 16 + 64;  // floats
-      if (!in_lds || pre || a.in_f64 || !rsg || !dl || ft.rsn_rounds > 2 || (plan->d.include_energy && ft.rs_eslot < 0) ||
+      if (!in_lds || !rsg || !dl || ft.rsn_rounds > 2 || (plan->d.include_energy && ft.rs_eslot < 0) || a.out_f64 ||
           staged > G::EXCH_F2 * 2) {
         set_error("stft_deltas_batch: not served for this plan and call (needs the row-segment filter walk with at "
-                  "most two rounds in LDS, float32 samples, no fused pre-emphasis)");
+                  "most two rounds in LDS and float32 features)");
         return PDS_ERR_INVALID;
       }
       mf = false;
-      kern = a.dl_K == 1 ? stft_wave_kernel<N1, N2, NROWS, 4 * DMINW, DMINW, true, false, false, 0, true, float, float, 1>
-                         : stft_wave_kernel<N1, N2, NROWS, 4 * DMINW, DMINW, true, false, false, 0, true, float, float, 2>;
-      dl_which = 18 + (a.dl_K - 1);
+      using D = double;
+      kern = a.in_f64 ? (pre ? stft_wave_kernel<N1, N2, NROWS, 4 * DMINW, DMINW, true, true, false, 0, true, D, float, 2>
+                             : stft_wave_kernel<N1, N2, NROWS, 4 * DMINW, DMINW, true, false, false, 0, true, D, float, 2>)
+                      : (pre ? stft_wave_kernel<N1, N2, NROWS, 4 * DMINW, DMINW, true, true, false, 0, true, float, float, 2>
+                             : stft_wave_kernel<N1, N2, NROWS, 4 * DMINW, DMINW, true, false, false, 0, true, float, float, 2>);
+      if (a.in_f64) {
+        p.win_half = ft.d_win_half;  // (twiddles regenerated from seeds, see the kernel)
+        p.tw_seed = (const float2 *)ft.d_tw_seed;
+      }
+      p.dl_order = a.dl_K;
+      dl_which = 18 + (a.in_f64 ? 1 : 0) + (pre ? 10 : 0);  // 18, 19, 28, 29
       for (int j = 0; j < 5; ++j) p.dl_f1[j] = (float)a.dl_taps[j];
       for (int j = 0; j < 9; ++j) p.dl_f2[j] = a.dl_K > 1 ? (float)a.dl_taps[5 + j] : 0.0f;
       p.dl_inner = plan->d.num_filts + (plan->d.include_energy ? 1 : 0);
       p.dl_eslot = plan->d.include_energy ? ft.rs_eslot : -1;
       p.chunk_prefix = a.d_chunk_prefix;
+      // (measurement builds only, -DPDS_DL_DEBUG_SWITCH=1: a stray environment variable must not be able to make a
+      // product launch skip its stores)
+#if defined(PDS_DL_DEBUG_SWITCH) && PDS_DL_DEBUG_SWITCH
       p.dl_debug = std::getenv("PDS_DL_DEBUG") ? std::atoi(std::getenv("PDS_DL_DEBUG")) : 0;
+#else
+      p.dl_debug = 0;
+#endif
     } else {
       set_error("stft_deltas_batch: no fused kernel for this transform size");
       return PDS_ERR_INVALID;

@@ -459,3 +459,98 @@ def test_launch_with_deltas_falls_back_to_two_launches():
     comp.launch(x, layout, out=want)
     d3.apply_rows(want[:, :C], layout.row_offsets, out=want)
     assert torch.equal(got, want)
+
+
+@pytest.mark.parametrize("K", [1, 2])
+@pytest.mark.parametrize("bank", ["fbank80_energy", "mel64_1024_energy"])
+@pytest.mark.parametrize("flow", ["f32+preemph", "f64", "f64+preemph"])
+def test_fused_statics_and_deltas_launch_with_preemphasis_and_float64_samples(K, bank, flow, monkeypatch):
+    """pds_stft_deltas_batch: the reference drivers' chain float64 audio -> Preemphasize -> compute_full -> Deltas
+    (command_line.py:345-350) as ONE launch, against the separate launches of the same kernels' plain forms (statics
+    within the feature tolerance of each other: the one-launch kernel regenerates its twiddles for float64 samples, the
+    deltas within a few float32 ulps of the statics) and against the oracle on the pre-emphasised signal"""
+    import torch
+
+    from oracle import stft_oracle as orc
+    from pydrobert_speech_amd import config
+    from pydrobert_speech_amd.alias import alias_factory_subclass_from_arg
+    from pydrobert_speech_amd.compute import FrameComputer
+    from tests.test_gpu_stft import _params_from_computer
+
+    cfg = {
+        "fbank80_energy": {"name": "stft", "bank": {"name": "fbank", "num_filts": 80}, "frame_length_ms": 25,
+                           "include_energy": True, "use_power": True},
+        "mel64_1024_energy": {"name": "stft", "bank": {"name": "tri", "scaling_function": "mel", "num_filts": 64,
+                                                       "sampling_rate": 48000},
+                              "frame_length_ms": 20, "include_energy": True, "use_power": True},
+    }[bank]
+    monkeypatch.setattr(config, "FLOAT64_ARITHMETIC", "float32")
+    comp = alias_factory_subclass_from_arg(FrameComputer, cfg)
+    plan = comp._native_plan()
+    assert plan.has_fused_deltas and plan.has_f64in
+    coeff = 0.97 if "preemph" in flow else 0.0
+    dt = "f8" if flow.startswith("f64") else "f4"
+    rng = np.random.default_rng(7 + K)
+    S, C = comp.frame_shift, comp.num_coeffs
+    deltas = Deltas(K)
+    lens = [0, S, 5 * S, 9 * S + 3, 60000, 33 * S, 1, 4 * S, 12 * S, 100 * S + 7, 2 * S]
+    host = (3000 * rng.standard_normal(int(np.sum(lens)))).astype(dt)
+    x = torch.from_numpy(host).cuda()
+    offs = np.concatenate([[0], np.cumsum(lens)[:-1]])
+    layout = comp.prepare_layout(offs, lens, device=x.device)
+    # poison the paths a silent fallback would take: the separate pre-emphasis pass and dtype conversions
+    one = torch.full((layout.total_rows, (K + 1) * C), float("nan"), device="cuda")
+    with monkeypatch.context() as m:
+        m.setattr(torch.Tensor, "to", lambda *a, **k: (_ for _ in ()).throw(AssertionError("conversion pass")))
+        got = comp.launch_with_deltas(x, layout, deltas, out=one, fused=True, preemphasis=coeff)
+    assert got.shape == (layout.total_rows, (K + 1) * C) and bool(torch.isfinite(one).all())
+    two = torch.empty_like(one)
+    comp.launch(x, layout, out=two, preemphasis=coeff)
+    deltas.apply_rows(two[:, :C], layout.row_offsets, out=two)
+    scale = float(two[:, :C].abs().max())
+    assert float((one[:, :C] - two[:, :C]).abs().max()) <= 1e-5 + 1e-4 * scale
+    # deltas of the launch's OWN statics, float64-accumulated
+    own = one.cpu().numpy()
+    p = _params_from_computer(comp)
+    for b, n in enumerate(lens):
+        rows = own[layout.row_offsets[b] : layout.row_offsets[b + 1]]
+        if not len(rows):
+            continue
+        ref = orc.deltas(rows[:, :C], axis=0, num_deltas=K, target_axis=-1)
+        assert np.abs(rows[:, C:] - ref[:, C:]).max() <= 4e-6 * max(scale, 1.0), (b, n)
+        sig = host[offs[b] : offs[b] + n].astype("f8")
+        if coeff:
+            sig = orc.preemphasize(sig, coeff)
+        want = orc.compute_full(sig.astype("f4"), p)
+        err = np.abs(rows[:, :C] - want)
+        # (pre-emphasised noise empties the lowest filters: the float32 floor of DESIGN.md section 2)
+        lin = np.abs(np.exp(rows[:, :C].astype("f8")) - np.exp(want.astype("f8")))
+        ok = (err <= 2e-5 + 2e-4 * np.abs(want)) | (lin <= 1e-6 * np.exp(want.astype("f8")).max(axis=1, keepdims=True))
+        assert ok.all(), (b, n, float(err.max()))
+
+
+def test_launch_with_deltas_float64_arithmetic_falls_back_to_float64_statics():
+    """float64 samples under the default config.FLOAT64_ARITHMETIC = "float64": the statics come from the float64
+    kernels and are rounded into the float32 rows (round 2 raised ValueError here)"""
+    import torch
+
+    from pydrobert_speech_amd.alias import alias_factory_subclass_from_arg
+    from pydrobert_speech_amd.compute import FrameComputer
+
+    comp = alias_factory_subclass_from_arg(FrameComputer, {"name": "stft", "bank": "fbank", "frame_length_ms": 25})
+    rng = np.random.default_rng(5)
+    lens = [4000, 801, 16000]
+    x = torch.from_numpy(3000 * rng.standard_normal(sum(lens))).cuda()
+    assert x.dtype == torch.float64
+    layout = comp.prepare_layout(np.concatenate([[0], np.cumsum(lens)[:-1]]), lens, device=x.device)
+    C = comp.num_coeffs
+    d = Deltas(2)
+    got = comp.launch_with_deltas(x, layout, d, preemphasis=0.97)
+    assert got.dtype == torch.float32 and got.shape == (layout.total_rows, 3 * C)
+    want = comp.launch(x, layout, preemphasis=0.97)
+    assert want.dtype == torch.float64
+    assert torch.equal(got[:, :C], want.to(torch.float32))
+    ref = torch.empty_like(got)
+    ref[:, :C] = got[:, :C]
+    d.apply_rows(ref[:, :C], layout.row_offsets, out=ref)
+    assert torch.equal(got, ref)

@@ -601,7 +601,7 @@ def test_ragged_scheduling_is_bit_identical(name, golden_meta, monkeypatch):
     monkeypatch.setattr(ps.config, "RAGGED_SCHEDULING", True)
     a = torch.full((layout.total_rows, comp.num_coeffs), float("nan"), device="cuda")
     comp.launch(x, layout, out=a)
-    assert layout.d_work is not None  # (the ragged launch ran)
+    assert layout.fill < 0.9  # (the ragged launch ran: its workspace is allocated per launch)
     monkeypatch.setattr(ps.config, "RAGGED_SCHEDULING", False)
     b = torch.full_like(a, float("nan"))
     comp.launch(x, layout, out=b)

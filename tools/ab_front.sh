@@ -1,7 +1,8 @@
 #!/bin/bash
 # GPU-box helper: A/B of the fused kernel's front ends on one box, interleaved:
 #   bash tools/ab_front.sh <workload> [<workload> ...]
-# PDS_STFT_FRONT=valu keeps the in-lane N1-point transform; default = matrix-pipe front end.
+# PDS_STFT_FRONT=mfma selects the matrix-pipe front end (libraries built with make EXTRA=-DPDS_EXPERIMENTS=1 only);
+# the default, and the only form of the product build, is the in-lane N1-point transform.
 cd ${GRAFT_REPO_ROOT:-/root/repo}
 for wl in "$@"; do
   for rep in 1 2 3; do
