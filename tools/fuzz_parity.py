@@ -64,13 +64,20 @@ def draw_si(rng):
     return cfg
 
 
+# what the float32-floor rule of close() let through in this process: elements compared under it, elements that
+# passed ONLY through it, and the worst ratio of such an element's error to the strict tolerance
+FLOOR = {"elements": 0, "exempted": 0, "worst_strict_ratio": 0.0, "comparisons_with_exemptions": 0}
+
+
 def close(got, want, rtol, atol, is_log=False):
     """|got - want| <= atol + rtol |want| per element -- or, for float32 arithmetic, inside the
     round-off floor of the frame: a coefficient 40 dB and more below the frame's largest one
     carries the FFT's float32 round-off (~1e-7 of the frame's amplitude) at full size, so its
     own relative error exceeds 1e-4 although the frame as a whole is as accurate as float32
     allows.  Such elements pass when their error is below 1e-6 of the frame's largest coefficient
-    (in the linear domain for log features)."""
+    (in the linear domain for log features).  Every element that passes only through this rule is
+    counted in FLOOR, with the worst ratio of its error to the strict tolerance: the summary line
+    prints them and tests/test_gpu_fuzz.py bounds them."""
     got, want = np.asarray(got, np.float64), np.asarray(want, np.float64)
     if got.shape != want.shape:
         return False, f"shape {got.shape} vs {want.shape}"
@@ -80,11 +87,19 @@ def close(got, want, rtol, atol, is_log=False):
     if (np.isnan(got) != nan).any():
         return False, "nan pattern"
     err = np.abs(got - want)
-    bad = (err > atol + rtol * np.abs(want)) & ~nan
-    if bad.any() and rtol > 1e-8 and want.ndim == 2:
-        lin_got, lin_want = (np.exp(got), np.exp(want)) if is_log else (got, want)
-        frame_peak = np.nanmax(np.abs(lin_want), axis=1, keepdims=True)
-        bad &= np.abs(lin_got - lin_want) > 1e-6 * frame_peak
+    tol = atol + rtol * np.abs(want)
+    bad = (err > tol) & ~nan
+    if rtol > 1e-8 and want.ndim == 2:
+        FLOOR["elements"] += int(want.size)
+        if bad.any():
+            lin_got, lin_want = (np.exp(got), np.exp(want)) if is_log else (got, want)
+            frame_peak = np.nanmax(np.abs(lin_want), axis=1, keepdims=True)
+            exempt = bad & (np.abs(lin_got - lin_want) <= 1e-6 * frame_peak)
+            if exempt.any():
+                FLOOR["exempted"] += int(exempt.sum())
+                FLOOR["comparisons_with_exemptions"] += 1
+                FLOOR["worst_strict_ratio"] = max(FLOOR["worst_strict_ratio"], float((err / tol)[exempt].max()))
+            bad &= ~exempt
     return (not bad.any()), f"{int(bad.sum())} bad, max err {np.nanmax(err):.3g}"
 
 
@@ -191,14 +206,21 @@ def main():
                     from pydrobert_speech_amd.post import Deltas
 
                     K = int(rng.integers(1, 3))
-                    xs = torch.from_numpy(np.concatenate(sigs)).cuda()
+                    # (round 3: float64 samples into the same launch in half of the draws that have the kernel)
+                    as64 = bool(plan.has_f64in and rng.random() < 0.5)
+                    xs = torch.from_numpy(np.concatenate(sigs).astype("f8" if as64 else "f4")).cuda()
                     offs = np.concatenate([[0], np.cumsum(lens)[:-1]])
                     layout = comp.prepare_layout(offs, lens, device=xs.device)
                     C = comp.num_coeffs
                     out = torch.full((layout.total_rows, (K + 1) * C), float("nan"), device="cuda")
-                    comp.launch_with_deltas(xs, layout, Deltas(K), out=out, fused=True)
+                    prev = ps.config.FLOAT64_ARITHMETIC
+                    ps.config.FLOAT64_ARITHMETIC = "float32"
+                    try:
+                        comp.launch_with_deltas(xs, layout, Deltas(K), out=out, fused=True)
+                    finally:
+                        ps.config.FLOAT64_ARITHMETIC = prev
                     mine = out.cpu().numpy()
-                    kinds["fused-deltas"] = kinds.get("fused-deltas", 0) + 1
+                    kinds["fused-deltas" + ("-f64in" if as64 else "")] = kinds.get("fused-deltas" + ("-f64in" if as64 else ""), 0) + 1
                     rows = layout.row_offsets
                     for b in range(len(lens)):
                         blk = mine[rows[b] : rows[b + 1]]
@@ -243,6 +265,9 @@ def main():
             traceback.print_exc()
     fails += fuzz_post(rng, max(1, count // 10))
     print("configs by kernel:", json.dumps(kinds, sort_keys=True), "failures:", fails)
+    print("float32-floor rule: %d of %d compared elements passed only through it (%d comparisons), worst error %.3g x "
+          "the strict tolerance" % (FLOOR["exempted"], FLOOR["elements"], FLOOR["comparisons_with_exemptions"],
+                                    FLOOR["worst_strict_ratio"]))
     return 1 if fails else 0
 
 
