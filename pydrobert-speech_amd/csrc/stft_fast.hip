@@ -358,7 +358,7 @@ int32_t fast_tables_create(pds_stft_plan *plan, const double *window, const int3
   if (rc == PDS_OK) rc = upload(&ft.d_ell_woff, ell_woff.data(), ell_woff.size());
   if (rc == PDS_OK) rc = upload(&ft.d_window, win.data(), win.size());
   if (rc == PDS_OK) rc = upload(&ft.d_twiddle, tw.data(), tw.size());
-  if ((n1 == 32 || n1 == 64) && n2 == 16) {
+  if (((n1 == 32 || n1 == 64) && n2 == 16) || lean_geometry(n1, n2)) {
     // float64-sample instantiations (and the prefetch experiment): window times 1/2 and the twiddle seeds
     // W_N^r, W_N^4r, W_N^(n1/4 r) (inl::twiddle_chain)
     std::vector<float> wh(win), seed((size_t)n2 * 6);

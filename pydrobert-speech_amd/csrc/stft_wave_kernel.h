@@ -98,17 +98,6 @@ extern unsigned long long *g_stamp_buf;  // (stft_fast.hip: pds_debug_set_stamp_
 #else
 #define PDS_STAMP(i, drain) do { } while (0)
 #endif
-// Experiment (tools/build_variant.sh -DPDS_STAGGER=1): the second half of a workgroup's waves (the SIMD
-// partners of the first half) runs half an item behind, held there by two workgroup barriers per item,
-// so that one partner's transform phase runs beside the other's filter phase.
-#ifndef PDS_STAGGER
-#define PDS_STAGGER 0
-#endif
-// Experiment (-DPDS_NT_STORE=1 | 2): non-temporal stores of the fused-deltas rows (1) and of the row-segment
-// walk's coefficients (2)
-#ifndef PDS_NT_STORE
-#define PDS_NT_STORE 0
-#endif
 // filter-walk depth of the geometries that run two waves per SIMD or fewer (256 registers and more)
 // (measured, tools/ab_libs.sh: segmented walk four steps deep at N = 1024, Gammatone-64 +3 %; ELL walk four
 // steps deep: N = 4096 +0.6 %, N = 2048 -0.5 %)
@@ -154,6 +143,9 @@ extern unsigned long long *g_stamp_buf;  // (stft_fast.hip: pds_debug_set_stamp_
 #endif
 #ifndef PDS_PF_TW
 #define PDS_PF_TW 1
+#endif
+#ifndef PDS_DLT_CHAIN  // (experiment: regenerated twiddles in the one-launch statics + deltas kernel, float32 samples too)
+#define PDS_DLT_CHAIN 0
 #endif
 #ifndef PDS_PF_WIN
 #define PDS_PF_WIN 0
@@ -269,11 +261,24 @@ __device__ __forceinline__ void wave_sync() {
 #ifndef PDS_TWOPASS
 #define PDS_TWOPASS 1
 #endif
+// Lean form of the 64 x 32 geometry (N = 2048: 25 ms frames at 48 kHz, two frames per wave).  With its window
+// slice (38 registers) and inter-stage twiddles (62) in registers it needs 209-235 of them and 17.4 KB of LDS per
+// wave: two waves per SIMD, 0.21 of the HBM roofline.  Lean: the twiddles are regenerated per item from three seeds
+// (inl::twiddle_chain<31>), the window slice is read from an LDS table where it is applied, and the exchange runs
+// in two passes -- real parts, then imaginary parts, through ONE float per element (9.2 KB per wave) -- so that
+// three waves per SIMD fit the registers and the LDS.  -DPDS_LEAN_2048=0: the form of rounds 1-2 (A/B builds).
+#ifndef PDS_LEAN_2048
+#define PDS_LEAN_2048 1
+#endif
+constexpr bool lean_geometry(int n1, int n2) { return PDS_LEAN_2048 && n1 == 64 && n2 == 32; }
 // floats of a wave's private LDS area (exchange, then power spectra + the walks' partial sums)
 constexpr int wave_area_floats(int n1, int n2) {
   const int cols = (n1 - 1) / 2 + 1, groups = 64 / n2, one_pass = groups * cols * (n2 + 2) * 2;
-  return (PDS_TWOPASS && n1 == 64 && n2 == 16) ? 3456 : one_pass;
+  return (PDS_TWOPASS && n1 == 64 && n2 == 16) ? 3456 : lean_geometry(n1, n2) ? groups * cols * (n2 + 4) : one_pass;
 }
+// floats of the window table a lean geometry keeps in LDS: [N2][stride], stride = 4 (mod 8) floats for
+// conflict-free 16-byte reads
+constexpr int win_table_stride(int rows) { return ((rows + 3) & ~3) % 8 == 4 ? ((rows + 3) & ~3) : ((rows + 3) & ~3) + 4; }
 
 template <int N1, int N2, int NROWS>
 struct WaveGeom {
@@ -288,9 +293,12 @@ struct WaveGeom {
   static constexpr int NB = N / 2 + 1;      // half-spectrum bins
   static constexpr int RS = N2 + 2;         // exchange row stride (float2): conflict-free
   static constexpr bool TWOPASS = PDS_TWOPASS && N1 == 64 && N2 == 16;
+  static constexpr bool LEAN = lean_geometry(N1, N2);    // regenerated twiddles, LDS window, real / imaginary exchange
+  static constexpr int RSF = N2 + 4;                     // LEAN: exchange row stride (floats)
   static constexpr int XROWS = TWOPASS ? N2 : COLS;      // rows of a frame's exchange block
   static constexpr int EXCH_F2 = wave_area_floats(N1, N2) / 2;  // float2 per wave (the wave's whole area)
-  static_assert(GROUPS * XROWS * RS <= EXCH_F2, "the exchange must fit the wave's area");
+  static_assert(LEAN ? GROUPS * XROWS * RSF <= EXCH_F2 * 2 : GROUPS * XROWS * RS <= EXCH_F2, "the exchange must fit the wave's area");
+  static_assert(!LEAN || (CPL == 1 && N2 >= 32), "lean form: one column per lane");
   // P row stride: >= NB + 1 (energy) and = 16 (mod 32) so that the two frames sharing a
   // 32-lane half write to disjoint banks
   static constexpr int PSTR = ((NB + 1 + 15) / 32) * 32 + 16;
@@ -394,6 +402,7 @@ __global__ __launch_bounds__(MAXWAVES * 64, MINW) void stft_wave_kernel(const Fa
   [[maybe_unused]] const unsigned long long st_entry = PDS_STAMPS ? __builtin_readcyclecounter() : 0;
   float *wbase = smem + wave * (G::EXCH_F2 * 2);
   float2 *exch = reinterpret_cast<float2 *>(wbase) + g * G::XROWS * RS;
+  [[maybe_unused]] float *xf = wbase + g * (G::XROWS * G::RSF);  // LEAN: the frame's exchange block, one float per element
   float *Pg = wbase + g * PSTR;
   // filter table -> LDS once per workgroup (read by every wave, every iteration): per-slot
   // weight rows.  Tables too large for LDS (dense complex banks) stay in global memory and
@@ -406,11 +415,12 @@ __global__ __launch_bounds__(MAXWAVES * 64, MINW) void stft_wave_kernel(const Fa
   // instantiations of the 16-lane geometries, whose 16-byte pair loads keep 4 registers per pair in flight (52 at 25
   // rows: with thirty registers of twiddles beside them the kernel spilled 10 ... 34 registers), and the prefetch
   // experiment
-  constexpr bool TWCHAIN = (PF && PDS_PF_TW == 1) || (PAIR && (N1 == 32 || N1 == 64));
-  constexpr bool WINLDS = PF && PDS_PF_WIN == 1;  // window slice re-read from LDS per item
-  constexpr int WSTR = ((NROWS + 3) & ~3) % 8 == 4 ? ((NROWS + 3) & ~3) : ((NROWS + 3) & ~3) + 4;  // row stride = 4 (mod 8) floats: conflict-free 16-byte reads
+  constexpr bool TWCHAIN = (PF && PDS_PF_TW == 1) || (PAIR && (N1 == 32 || N1 == 64)) || (PDS_DLT_CHAIN && DLT > 0 && N1 == 32 && N2 == 16) || G::LEAN;
+  constexpr bool WINLDS = PF && PDS_PF_WIN == 1;  // window slice re-read from LDS per item (in front of the item: prefetch experiment)
+  constexpr bool WINUSE = G::LEAN;                // ... read from LDS where it is applied
+  constexpr int WSTR = win_table_stride(NROWS);
   [[maybe_unused]] float *win_lds = ellw_lds + (ELL_LDS ? p.ell_wfloats : 0);  // [N2][WSTR]
-  if constexpr (WINLDS) {
+  if constexpr (WINLDS || WINUSE) {
     const float *wsrc = TWCHAIN ? p.win_half : p.win_lane;
     for (int i = threadIdx.x; i < N2 * WSTR; i += p.waves * 64) {
       const int rr = i / WSTR, k = i - rr * WSTR;
@@ -458,7 +468,7 @@ __global__ __launch_bounds__(MAXWAVES * 64, MINW) void stft_wave_kernel(const Fa
 
   // per-lane constants, loop invariant: window slice and inter-stage twiddles (issued in front of the LDS
   // set-up instead: measured slower, 0.0328 against 0.0308 ms at 64 utterances)
-  [[maybe_unused]] float win[(MF || WINLDS) ? 1 : NROWS];
+  [[maybe_unused]] float win[(MF || WINLDS || WINUSE) ? 1 : NROWS];
   [[maybe_unused]] float twr[(MF || TWCHAIN) ? 1 : COLS], twi[(MF || TWCHAIN) ? 1 : COLS];
   [[maybe_unused]] float sd[6] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};  // TWCHAIN: the seeds W^r, W^4r, W^8r
   // MF: window and byte offset of the lane's sample slots, A operands of the two chains, twiddles of
@@ -484,7 +494,7 @@ __global__ __launch_bounds__(MAXWAVES * 64, MINW) void stft_wave_kernel(const Fa
       mtwi[v] = t.y;
     }
   } else {
-    if constexpr (!WINLDS) {
+    if constexpr (!WINLDS && !WINUSE) {
       const float *wsrc = TWCHAIN ? p.win_half : p.win_lane;
 #pragma unroll
       for (int n1 = 0; n1 < NROWS; ++n1) win[n1] = wsrc[rho * N1 + n1];
@@ -690,11 +700,7 @@ __global__ __launch_bounds__(MAXWAVES * 64, MINW) void stft_wave_kernel(const Fa
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
             F4 o = {val[q].x, val[q].y, val[q].z, val[q].w};
-#if PDS_NT_STORE & 1
-            __builtin_nontemporal_store(o, reinterpret_cast<F4 *>(orow + (int64_t)q * p.out_stride + 4 * l));
-#else
             *reinterpret_cast<F4 *>(orow + (int64_t)q * p.out_stride + 4 * l) = o;
-#endif
           }
         }
       } else {
@@ -719,9 +725,6 @@ __global__ __launch_bounds__(MAXWAVES * 64, MINW) void stft_wave_kernel(const Fa
     }
     wave_sync();
   };
-  if constexpr (PDS_STAGGER) {
-    if (b < p.num_utts && (wave & 4)) __builtin_amdgcn_s_barrier();
-  }
   [[maybe_unused]] unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   [[maybe_unused]] unsigned long long st_prev = PDS_STAMPS ? __builtin_readcyclecounter() : 0;
   [[maybe_unused]] const unsigned long long st_loop = st_prev;
@@ -1142,6 +1145,16 @@ __global__ __launch_bounds__(MAXWAVES * 64, MINW) void stft_wave_kernel(const Fa
       if constexpr (WINLDS) {
 #pragma unroll
         for (int n1 = 0; n1 < NROWS; ++n1) a[n1] = mul_legacy(a[n1], wl[n1]);
+      } else if constexpr (WINUSE) {
+        const float4 *w4 = reinterpret_cast<const float4 *>(win_lds + rho * WSTR);
+#pragma unroll
+        for (int j = 0; j < (NROWS + 3) / 4; ++j) {
+          const float4 w = w4[j];
+          const float wv[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+          for (int u = 0; u < 4; ++u)
+            if (4 * j + u < NROWS) a[4 * j + u] = mul_legacy(a[4 * j + u], wv[u]);
+        }
       } else {
 #pragma unroll
         for (int n1 = 0; n1 < NROWS; ++n1) a[n1] = mul_legacy(a[n1], win[n1]);
@@ -1169,7 +1182,14 @@ __global__ __launch_bounds__(MAXWAVES * 64, MINW) void stft_wave_kernel(const Fa
       // N1: c[j] = sum_q xw[j + N2 q] for j < N2 and zeros above, whose 2 N2-point transform has
       // the multiples of N1 at its even outputs; the odd ones are not bins and are dropped.)
       PDS_PHASE(1);
-      {
+      // LEAN: real parts now, imaginary parts (kept in Ai) behind the column reads of the real ones.  Row 0 holds the
+      // packed sums z[m] = c[2 m] + i c[2 m + 1], c = (even sums, odd sums): lane 2 m supplies the real part of
+      // elements m and N2 / 2 + m, lane 2 m + 1 their imaginary part; the other lanes write to the row's padding.
+      if constexpr (G::LEAN) {
+        const int slot = (rho & 1) ? N2 + (rho & 3) : (rho >> 1);
+        xf[slot] = even_sum;
+        xf[(rho & 1) ? N2 + (rho & 3) : N2 / 2 + (rho >> 1)] = odd_sum;
+      } else {
         float *row0 = reinterpret_cast<float *>(exch);
         row0[rho] = even_sum;
         row0[N2 + rho] = odd_sum;
@@ -1196,13 +1216,15 @@ __global__ __launch_bounds__(MAXWAVES * 64, MINW) void stft_wave_kernel(const Fa
           // two-pass exchange: the second half of the columns waits, twiddled, for the first half's transforms
           Ar[k1] = v.x;
           Ai[k1] = v.y;
+        } else if constexpr (G::LEAN) {
+          xf[k1 * G::RSF + rho] = v.x;
+          Ai[k1] = v.y;
         } else {
           exch[k1 * RS + rho] = v;
         }
       }
     }
     PDS_STAMP(2, 0);  // window, N1-point transform, twiddles, exchange stores issued
-    if constexpr (PDS_STAGGER) __builtin_amdgcn_s_barrier();
     wave_sync();
 
     float pw[G::CPL][N2 + 1];
@@ -1292,6 +1314,29 @@ __global__ __launch_bounds__(MAXWAVES * 64, MINW) void stft_wave_kernel(const Fa
       }
       const float4 *row = reinterpret_cast<const float4 *>(exch + (G::TWOPASS ? r : kk) * RS);
       float zr[N2], zi[N2], Yr[N2], Yi[N2];
+      if constexpr (G::LEAN) {
+        // the column's real parts; then the imaginary parts take the same rows
+        const float4 *rowf = reinterpret_cast<const float4 *>(xf + r * G::RSF);
+#pragma unroll
+        for (int j = 0; j < N2 / 4; ++j) {
+          const float4 v = rowf[j];
+          zr[4 * j] = v.x, zr[4 * j + 1] = v.y, zr[4 * j + 2] = v.z, zr[4 * j + 3] = v.w;
+        }
+        wave_sync();
+        {
+          const int slot = (rho & 1) ? (rho >> 1) : N2 + (rho & 3);
+          xf[slot] = even_sum;
+          xf[(rho & 1) ? N2 / 2 + (rho >> 1) : N2 + (rho & 3)] = odd_sum;
+        }
+#pragma unroll
+        for (int k1 = 1; k1 <= NREG; ++k1) xf[k1 * G::RSF + rho] = Ai[k1];
+        wave_sync();
+#pragma unroll
+        for (int j = 0; j < N2 / 4; ++j) {
+          const float4 v = rowf[j];
+          zi[4 * j] = v.x, zi[4 * j + 1] = v.y, zi[4 * j + 2] = v.z, zi[4 * j + 3] = v.w;
+        }
+      } else
 #pragma unroll
       for (int j = 0; j < N2 / 2; ++j) {
         float4 v;
@@ -1360,12 +1405,14 @@ __global__ __launch_bounds__(MAXWAVES * 64, MINW) void stft_wave_kernel(const Fa
         } else {
           // other group sizes: lane 0 hands its column over through row 0 of the frame's exchange
           // block (its only reader, lane 0 itself, is past it)
+          // (LEAN: the frame's block is addressed in floats; its first 2 N2 of them take the column)
+          float2 *hand = G::LEAN ? reinterpret_cast<float2 *>(xf) : exch;
           if (r == 0) {
 #pragma unroll
-            for (int k2 = 0; k2 < N2; ++k2) exch[k2] = make_float2(Yr[k2], Yi[k2]);
+            for (int k2 = 0; k2 < N2; ++k2) hand[k2] = make_float2(Yr[k2], Yi[k2]);
           }
           wave_sync();
-          const float2 ya = exch[r], yb = exch[(N2 - r) & (N2 - 1)];
+          const float2 ya = hand[r], yb = hand[(N2 - r) & (N2 - 1)];
           ar = ya.x, ai = ya.y, br = yb.x, bi = yb.y;
         }
         const float sr = ar + br, si = ai - bi;
@@ -1637,11 +1684,7 @@ __global__ __launch_bounds__(MAXWAVES * 64, MINW) void stft_wave_kernel(const Fa
           float v = vals[gg];
           // max(val, floor) as Python evaluates it: a NaN stays a NaN (compute.py:459)
           if (p.use_log) v = fast_log(p.log_floor > v ? p.log_floor : v);
-#if PDS_NT_STORE & 2
-          if (DLT == 0 && f >= 0 && gg < frames_here) __builtin_nontemporal_store((TOUT)v, dst + (int64_t)gg * p.out_stride);
-#else
           if (DLT == 0 && f >= 0 && gg < frames_here) dst[(int64_t)gg * p.out_stride] = (TOUT)v;
-#endif
           logged[gg] = v;
         }
       };
@@ -1682,7 +1725,6 @@ __global__ __launch_bounds__(MAXWAVES * 64, MINW) void stft_wave_kernel(const Fa
         ++chunk;
       }
       PDS_STAMP(5, 0);  // filter walk
-      if constexpr (PDS_STAGGER) __builtin_amdgcn_s_barrier();
       wave_sync();
       continue;
     }
@@ -1866,7 +1908,6 @@ __global__ __launch_bounds__(MAXWAVES * 64, MINW) void stft_wave_kernel(const Fa
           }
         }
         PDS_STAMP(5, 0);  // filter walk
-      if constexpr (PDS_STAGGER) __builtin_amdgcn_s_barrier();
         wave_sync();
         continue;
       }
@@ -1877,7 +1918,6 @@ __global__ __launch_bounds__(MAXWAVES * 64, MINW) void stft_wave_kernel(const Fa
     for (int sl = USLOTS; sl < p.ell_slots; ++sl)
       run_slot(meta_lds[sl * N2 + r], load_const(p.ell_len + sl), load_const(p.ell_woff + sl));
     PDS_STAMP(5, 0);  // filter walk
-      if constexpr (PDS_STAGGER) __builtin_amdgcn_s_barrier();
     wave_sync();
   }
   if constexpr (PDS_STAMPS) {
@@ -1909,7 +1949,10 @@ int32_t launch_wave(const pds_stft_plan *plan, const BatchArgs &a) {
   using G = WaveGeom<N1, N2, NROWS>;
   // resident waves per CU that the register budget allows; the fused statics + deltas instantiations
   // hold their window in registers and run three waves per SIMD where the others run four
-  constexpr int DMINW = MINW > 3 ? 3 : MINW;
+#ifndef PDS_DLT_MINW  // (experiment: 4 = the one-launch statics + deltas kernel at four waves per SIMD, twiddles regenerated)
+#define PDS_DLT_MINW 3
+#endif
+  constexpr int DMINW = MINW > PDS_DLT_MINW ? PDS_DLT_MINW : MINW;
   constexpr int CU_WAVES_STFT = 4 * MINW;
   const int CU_WAVES = a.dl_K > 0 ? 4 * DMINW : CU_WAVES_STFT;
   const FastTables &ft = plan->fast;
@@ -1924,8 +1967,8 @@ int32_t launch_wave(const pds_stft_plan *plan, const BatchArgs &a) {
   p.win_lane = ft.d_window;
   p.tw_lane = (const float2 *)ft.d_twiddle;
   p.tw_special = (const float2 *)ft.d_tw_special;
-  p.win_half = nullptr;
-  p.tw_seed = nullptr;
+  p.win_half = G::LEAN ? ft.d_win_half : nullptr;  // (lean geometries: every instantiation regenerates its twiddles)
+  p.tw_seed = G::LEAN ? (const float2 *)ft.d_tw_seed : nullptr;
   p.ell_w = ft.d_ell_w;
   p.ell_meta = ft.d_ell_meta;
   p.ell_len = ft.d_ell_len;
@@ -1989,6 +2032,7 @@ int32_t launch_wave(const pds_stft_plan *plan, const BatchArgs &a) {
                      ft.d_tw_seed && !(pf_env && pf_env[0] == '0');
   constexpr int PF_WSTR = ((NROWS + 3) & ~3) % 8 == 4 ? ((NROWS + 3) & ~3) : ((NROWS + 3) & ~3) + 4;
   const size_t pf_extra = (PDS_PF_WIN == 1) ? (size_t)N2 * PF_WSTR * 4 : 0;  // window table in LDS
+  const size_t lean_extra = G::LEAN ? (size_t)N2 * win_table_stride(NROWS) * 4 : 0;  // ... of the lean geometries
   constexpr bool MSG = G::GROUPS == 4 && inl::is_pow2(N1);  // matrix-pipe segment walk instantiated
   constexpr bool SEGOK = G::GROUPS == 4 || (inl::is_pow2(N1) && N2 >= 32);  // segmented walk instantiated
   for (int cand = (G::GROUPS == 4) ? (dl ? 2 : ft.walk) : (SEGOK && ft.walk == 1 ? 1 : 0); cand >= 0 && !in_lds; --cand) {
@@ -1997,7 +2041,7 @@ int32_t launch_wave(const pds_stft_plan *plan, const BatchArgs &a) {
     if ((cand == 2 && !dl && ft.rs_rounds == 0) || (cand == 1 && (ft.seg_rounds == 0 || pre || a.in_f64))) continue;
     const int meta_ints = cand == 3 ? ft.ms_meta_ints : cand == 2 ? (dl ? ft.rsn_rounds : ft.rs_rounds) * 64 : cand == 1 ? ft.seg_meta_ints : ft.ell_slots * N2;
     const int meta_pad = (std::max(meta_ints, USLOTS * N2) + 3) / 4 * 4;
-    const size_t fixed = (size_t)N2 * 8 + (size_t)meta_pad * 4 + (cand == 2 && pf_ok ? pf_extra : 0);
+    const size_t fixed = (size_t)N2 * 8 + (size_t)meta_pad * 4 + (cand == 2 && pf_ok ? pf_extra : 0) + lean_extra;
     const size_t table_bytes = (size_t)(cand == 3 ? ft.ms_wfloats : cand == 2 ? (dl ? ft.rsn_wfloats : ft.rs_wfloats) : cand == 1 ? ft.seg_wfloats : ft.ell_wfloats) * 4;
     // (segment sums live behind P in the wave's area)
     if (cand == 1 && (size_t)G::GROUPS * G::PSTR * 4 + (size_t)ft.seg_rounds * 64 * 4 * G::GROUPS > per_wave) continue;
@@ -2035,7 +2079,7 @@ int32_t launch_wave(const pds_stft_plan *plan, const BatchArgs &a) {
 #ifdef PDS_FORCE_WAVES  // (experiment: throughput against resident waves per CU, two workgroups per CU)
   if (in_lds && PDS_FORCE_WAVES <= CU_WAVES / 2) waves = PDS_FORCE_WAVES, wgs_per_cu = 2;
 #endif
-  const size_t fixed = (size_t)N2 * 8 + (size_t)p.ell_meta_pad * 4 + (walk == 2 && in_lds && pf_ok ? pf_extra : 0);
+  const size_t fixed = (size_t)N2 * 8 + (size_t)p.ell_meta_pad * 4 + (walk == 2 && in_lds && pf_ok ? pf_extra : 0) + lean_extra;
   const size_t table_bytes = (size_t)p.ell_wfloats * 4;
   // the fused pre-emphasis variant exists for LDS-resident tables only; the rare other case
   // (dense complex bank at N >= 1024 plus pre-emphasis) takes the direct-DFT kernel
@@ -2154,7 +2198,7 @@ int32_t launch_wave(const pds_stft_plan *plan, const BatchArgs &a) {
                              : stft_wave_kernel<N1, N2, NROWS, 4 * DMINW, DMINW, true, false, false, 0, true, D, float, 2>)
                       : (pre ? stft_wave_kernel<N1, N2, NROWS, 4 * DMINW, DMINW, true, true, false, 0, true, float, float, 2>
                              : stft_wave_kernel<N1, N2, NROWS, 4 * DMINW, DMINW, true, false, false, 0, true, float, float, 2>);
-      if (a.in_f64) {
+      if (a.in_f64 || PDS_DLT_CHAIN) {
         p.win_half = ft.d_win_half;  // (twiddles regenerated from seeds, see the kernel)
         p.tw_seed = (const float2 *)ft.d_tw_seed;
       }

@@ -50,7 +50,7 @@ DEFAULT_PATH = [
     _key(64, 16, 60, 8, 2),                                   # 20 ms frames at 48 kHz, mel bank
     _key(64, 16, 60, 8, 2, tin="d"),
     _key(64, 16, 60, 8, 2, pre="T", tin="d"),
-    _key(64, 32, 38, 8, 2, rsg="F"),                          # 25 ms frames at 48 kHz (N = 2048)
+    _key(64, 32, 38, 12, 3, rsg="F"),                         # 25 ms frames at 48 kHz (N = 2048, lean form)
 ]
 
 
