@@ -171,12 +171,14 @@ int32_t pds_stft_plan_has_fused_deltas(const pds_stft_plan *plan);
  * float32 (signal_is_f64 = 0) or float64 samples (1: plans with pds_stft_plan_has_f64in(); rounded to float32 as the
  * frame is loaded, as in pds_stft_batch_f64in) and a fused pre-emphasis (`preemph` != 0, pre.py:140-149: in the
  * signal's own precision, before the rounding).  float64 audio -> Preemphasize -> compute_full -> Deltas in one
- * launch; features float32. */
+ * launch; features float32.  workspace_prepared != 0: d_workspace already holds the batch's chunk prefix sums
+ * (pds_stft_prepare_chunk_prefix(), see pds_stft_cmvn_batch_f32) and no kernel runs in front. */
 int32_t pds_stft_deltas_batch(const pds_stft_plan *plan, const void *d_signal, int32_t signal_is_f64,
                               const int64_t *d_offsets, const int64_t *d_lengths, const int64_t *d_nframes,
                               const int64_t *d_row_off, int32_t B, int64_t max_frames, int32_t pad_left,
                               double preemph, int32_t num_deltas, int32_t context_window, const double *taps,
-                              int64_t *d_workspace, float *d_out, int64_t out_stride, void *stream);
+                              int64_t *d_workspace, int32_t workspace_prepared, float *d_out, int64_t out_stride,
+                              void *stream);
 /* (float32 samples, no pre-emphasis: the round-2 signature) */
 int32_t pds_stft_deltas_batch_f32(const pds_stft_plan *plan, const float *d_signal,
                                   const int64_t *d_offsets, const int64_t *d_lengths,
@@ -184,6 +186,31 @@ int32_t pds_stft_deltas_batch_f32(const pds_stft_plan *plan, const float *d_sign
                                   int64_t max_frames, int32_t pad_left, int32_t num_deltas,
                                   int32_t context_window, const double *taps, int64_t *d_workspace,
                                   float *d_out, int64_t out_stride, void *stream);
+/* compute_full followed by per-utterance CMVN (reference post.py:250-295, "local" statistics; BASELINE.json
+ * configs[4]) with the SUMS taken by the STFT launch: every wave walks one contiguous stretch of the batch's chunks
+ * (as in pds_stft_batch_ragged_f32), adds the coefficients it stores to float64 sums of its own and leaves them per
+ * piece of an utterance in the workspace; the normalising kernel adds an utterance's pieces in wave order
+ * (deterministic, like pds_cmvn_rows_f32's fixed-order sums, though not the same order) and reads the float32
+ * features ONCE: x * scale - shift into d_out (float64 like the reference's, or float32).  d_feats receives the
+ * float32 features (num_coeffs columns, row stride feats_stride), d_stats [B][2][num_coeffs] the sums.
+ * d_chunk_prefix: B + 1 int64 on the device -- filled by a small kernel in front of the main one, or, with
+ * prefix_prepared != 0, already holding what pds_stft_prepare_chunk_prefix() left there for this batch (the prefix
+ * sums depend on d_nframes only: prepare them once with the batch's other index arrays, share them between launches).
+ * d_partials: scratch of pds_stft_cmvn_partials_len(plan, B) float64, rewritten by every launch.  Served for the
+ * 16-lane power-of-two geometries (N = 512, 1024) whose plan takes a segment walk with registers to spare, when the
+ * waves' sums fit in LDS beside its tables (else PDS_ERR_INVALID: use pds_stft_batch_f32 + pds_cmvn_rows_f32);
+ * float32 samples, no fused pre-emphasis. */
+int32_t pds_stft_plan_has_fused_cmvn(const pds_stft_plan *plan);
+int64_t pds_stft_cmvn_partials_len(const pds_stft_plan *plan, int32_t B);
+int32_t pds_stft_prepare_chunk_prefix(const pds_stft_plan *plan, const int64_t *d_nframes, int32_t B,
+                                      int64_t *d_chunk_prefix, void *stream);
+int32_t pds_stft_cmvn_batch_f32(const pds_stft_plan *plan, const float *d_signal, const int64_t *d_offsets,
+                                const int64_t *d_lengths, const int64_t *d_nframes, const int64_t *d_row_off,
+                                int32_t B, int64_t max_frames, int32_t pad_left, int32_t norm_var,
+                                int64_t *d_chunk_prefix, int32_t prefix_prepared, double *d_partials,
+                                int64_t partials_len, float *d_feats, int64_t feats_stride, double *d_stats,
+                                void *d_out, int32_t out_is_f64, int64_t out_stride, int32_t *d_zero_var,
+                                void *stream);
 /* float32 input through the generic kernels regardless of N: radix-2 FFT in LDS for powers of two,
  * direct DFT otherwise (cross-check of the fused kernel; also what sizes without a fused geometry use) */
 int32_t pds_stft_batch_f32_generic(const pds_stft_plan *plan, const float *d_signal,

@@ -104,10 +104,18 @@ SIGNATURES = {
     "pds_stft_batch_f32_generic": (c_int32, _BATCH_ARGS),
     "pds_stft_plan_has_f64in": (c_int32, [c_void_p]),
     "pds_stft_plan_has_fused_deltas": (c_int32, [c_void_p]),
+    "pds_stft_plan_has_fused_cmvn": (c_int32, [c_void_p]),
+    "pds_stft_cmvn_partials_len": (c_int64, [c_void_p, c_int32]),
+    "pds_stft_prepare_chunk_prefix": (c_int32, [c_void_p, c_void_p, c_int32, c_void_p, c_void_p]),
+    "pds_stft_cmvn_batch_f32": (
+        c_int32,
+        [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int64, c_int32, c_int32, c_void_p,
+         c_int32, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_int32, c_int64, c_void_p, c_void_p],
+    ),
     "pds_stft_deltas_batch": (
         c_int32,
         [c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int64, c_int32, c_double,
-         c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_int64, c_void_p],
+         c_int32, c_int32, c_void_p, c_void_p, c_int32, c_void_p, c_int64, c_void_p],
     ),
     "pds_stft_deltas_batch_f32": (
         c_int32,

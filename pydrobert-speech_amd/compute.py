@@ -175,6 +175,21 @@ class PackedLayout:
         # that deals the existing chunks evenly (pds_stft_batch_ragged_f32)
         top = int(nframes.max()) if B else 0
         self.fill = float(nframes.sum()) / (top * B) if top else 1.0
+        # chunk prefix sums of the stretch-scheduled launches (statics + deltas, fused CMVN sums), per fused geometry
+        # of the plan: index data like d_meta, computed on the device once per layout and read-only after
+        self._chunk_prefix = {}
+
+    def chunk_prefix(self, plan, lib, torch, stream):
+        """device int64[B + 1]: chunks of the plan's frames-per-wave in front of every utterance
+        (``pds_stft_prepare_chunk_prefix``); cached -- a layout's index data never changes"""
+        key = (int(plan.kernel_kind), self.d_meta.device)  # (the frames per wave follow from the fused geometry)
+        hit = self._chunk_prefix.get(key)
+        if hit is None:
+            hit = torch.empty(self.B + 1, dtype=torch.int64, device=self.d_meta.device)
+            _native.check(lib.pds_stft_prepare_chunk_prefix(plan.handle, self.d_meta[2].data_ptr(), self.B,
+                                                            hit.data_ptr(), stream), "pds_stft_prepare_chunk_prefix")
+            self._chunk_prefix[key] = hit
+        return hit
 
     @property
     def total_rows(self) -> int:
@@ -202,6 +217,8 @@ class _NativePlan:
         self.kernel_kind = lib.pds_stft_plan_kernel_kind(handle)
         self.has_f64in = bool(lib.pds_stft_plan_has_f64in(handle))
         self.has_fused_deltas = bool(lib.pds_stft_plan_has_fused_deltas(handle))
+        self.has_fused_cmvn = bool(lib.pds_stft_plan_has_fused_cmvn(handle))
+
 
     def __del__(self):
         handle, self.handle = getattr(self, "handle", None), None
@@ -560,14 +577,17 @@ class ShortTimeFourierTransformFrameComputer(LinearFilterBankFrameComputer):
             pad = -1 if pad_left is None else int(pad_left)
             meta = layout.d_meta
             with torch.cuda.device(signal.device):
-                work = torch.empty(min(layout.B, _MAX_UTTS_PER_CALL) + 1, dtype=torch.int64, device=signal.device)
+                # (one call: the layout's prepared chunk prefix sums; more: a workspace the kernel in front fills)
+                single = layout.B <= _MAX_UTTS_PER_CALL
+                work = (layout.chunk_prefix(plan, lib, torch, stream) if single else
+                        torch.empty(min(layout.B, _MAX_UTTS_PER_CALL) + 1, dtype=torch.int64, device=signal.device))
                 for lo in range(0, layout.B, _MAX_UTTS_PER_CALL):
                     hi = min(layout.B, lo + _MAX_UTTS_PER_CALL)
                     rc = lib.pds_stft_deltas_batch(
                         plan.handle, signal.data_ptr(), int(signal.dtype == torch.float64), meta[0, lo:].data_ptr(),
                         meta[1, lo:].data_ptr(), meta[2, lo:].data_ptr(), meta[3, lo:].data_ptr(), hi - lo,
                         int(layout.nframes[lo:hi].max()), pad, float(preemphasis), K, 2, taps.ctypes.data,
-                        work.data_ptr(), out.data_ptr(), out.stride(0), stream,
+                        work.data_ptr(), int(single), out.data_ptr(), out.stride(0), stream,
                     )
                     if rc != 0 and lo == 0:
                         fused = False  # (e.g. a filter table that does not fit in LDS): the two launches below
@@ -582,6 +602,79 @@ class ShortTimeFourierTransformFrameComputer(LinearFilterBankFrameComputer):
             if total:
                 deltas.apply_rows(out[:, :C], layout.row_offsets, out=out)
         return out[:, : (K + 1) * C] if out.shape[1] != (K + 1) * C else out
+
+    def launch_with_cmvn(self, signal, layout: "PackedLayout", cmvn, out=None, pad_left=None,
+                         fused: Optional[bool] = None, out_dtype=None, feats_out=None):
+        """Features of a packed batch standardised per utterance (``cmvn``: a :class:`pydrobert_speech_amd.post.CMVN`
+        without global statistics): :func:`launch` followed by ``cmvn.apply_rows``, float64 result like the
+        reference's (``post.py:250-295``), float32 with ``out_dtype=torch.float32``.
+
+        ``fused=True`` asks for the form in which the STFT launch takes the sums itself where the plan has it
+        (``pds_stft_cmvn_batch_f32``: every wave adds what it stores to float64 sums of its own, the normalising
+        kernel adds an utterance's pieces in a fixed order and reads the features once instead of twice: 770 MB of
+        HBM traffic instead of 835 on BASELINE.json configs[4]).  It is NOT the default: measured on that workload
+        the sums cost the (vector-bound) STFT kernel 2.9 us and save the (write-bound) normalising kernel 3.1 us, and
+        the step comes out 1 % slower than the two calls (0.289 against 0.285 ms).  ``fused=None`` / ``False``,
+        float64 signals, or a plan / call the kernel does not serve: the two calls.
+        `feats_out`: optional ``(>= total_rows, >= num_coeffs)`` float32 tensor that receives the features
+        themselves (else they live in a temporary).
+        """
+        torch = _native.require_device()
+        lib = _native.lib()
+        if cmvn.have_stats:
+            raise ValueError("launch_with_cmvn standardises locally; global statistics are set")
+        C, total = self.num_coeffs, layout.total_rows
+        out_dtype = torch.float64 if out_dtype is None else out_dtype
+        if out_dtype not in (torch.float32, torch.float64):
+            raise ValueError("out_dtype must be float32 or float64")
+        if out is None:
+            out = torch.empty((total, C), dtype=out_dtype, device=signal.device)
+        elif out.dtype != out_dtype or out.dim() != 2 or out.shape[0] < total or out.shape[1] < C or out.stride(1) != 1:
+            raise ValueError("out has the wrong dtype, shape or strides")
+        plan = self._native_plan(signal.device)
+        use = bool(fused) and plan.has_fused_cmvn and signal.dtype == torch.float32 and total > 0 \
+            and layout.B <= _MAX_UTTS_PER_CALL
+        if use:
+            if not signal.is_cuda or signal.dim() != 1 or not signal.is_contiguous():
+                raise ValueError("signal must be a contiguous 1-D tensor on the GPU")
+            if layout.extent > signal.numel():
+                raise ValueError("an utterance lies outside the signal buffer")
+            stream = torch.cuda.current_stream(signal.device).cuda_stream
+            pad = -1 if pad_left is None else int(pad_left)
+            meta = layout.d_meta
+            with torch.cuda.device(signal.device):
+                prefix = layout.chunk_prefix(plan, lib, torch, stream)
+                plen = int(lib.pds_stft_cmvn_partials_len(plan.handle, layout.B))
+                partials = torch.empty(plen, dtype=torch.float64, device=signal.device)  # (scratch of this launch)
+                if feats_out is None:
+                    feats = torch.empty((total, C), dtype=torch.float32, device=signal.device)
+                else:
+                    feats = feats_out
+                    if (feats.dtype != torch.float32 or feats.dim() != 2 or feats.shape[0] < total or feats.shape[1] < C
+                            or feats.stride(1) != 1 or not feats.is_cuda):
+                        raise ValueError("feats_out has the wrong dtype, shape or strides")
+                stats = torch.empty((layout.B, 2, C), dtype=torch.float64, device=signal.device)
+                zero_var = torch.zeros(1, dtype=torch.int32, device=signal.device)
+                rc = lib.pds_stft_cmvn_batch_f32(
+                    plan.handle, signal.data_ptr(), meta[0].data_ptr(), meta[1].data_ptr(), meta[2].data_ptr(),
+                    meta[3].data_ptr(), layout.B, int(layout.nframes.max()), pad, int(cmvn._norm_var), prefix.data_ptr(),
+                    1, partials.data_ptr(), plen, feats.data_ptr(), feats.stride(0), stats.data_ptr(), out.data_ptr(),
+                    int(out_dtype == torch.float64), out.stride(0), zero_var.data_ptr(), stream,
+                )
+            if rc == 0:
+                cmvn._last_zero_var = zero_var
+                return out[:total, :C] if out.shape != (total, C) else out
+            # (e.g. no room in LDS for the waves' sums beside the filter table): the two calls below
+        if feats_out is not None and signal.dtype == torch.float32:
+            feats = self.launch(signal, layout, pad_left=pad_left, out=feats_out)[:total, :C]
+        else:
+            feats = self.launch(signal, layout, pad_left=pad_left)
+        if feats.dtype != torch.float32:
+            feats = feats.to(torch.float32)
+        res = cmvn.apply_rows(feats, layout.row_offsets, out_dtype=out_dtype)
+        if total:
+            out[:total, :C] = res
+        return out[:total, :C] if out.shape != (total, C) else out
 
     def compute_packed(self, signal, offsets, lengths, nframes=None, pad_left=None, out=None,
                        generic=False, preemphasis: float = 0.0):

@@ -230,7 +230,7 @@ int32_t pds_stft_deltas_batch(const pds_stft_plan *plan, const void *d_signal, i
                               const int64_t *d_offsets, const int64_t *d_lengths, const int64_t *d_nframes,
                               const int64_t *d_row_off, int32_t B, int64_t max_frames, int32_t pad_left, double preemph,
                               int32_t num_deltas, int32_t context_window, const double *taps, int64_t *d_workspace,
-                              float *d_out, int64_t out_stride, void *stream) {
+                              int32_t workspace_prepared, float *d_out, int64_t out_stride, void *stream) {
   int32_t rc = check_batch(plan, d_signal, d_offsets, d_lengths, d_nframes, d_row_off, B, max_frames, pad_left,
                            d_out, out_stride);
   if (rc == 1) return PDS_OK;
@@ -250,6 +250,7 @@ int32_t pds_stft_deltas_batch(const pds_stft_plan *plan, const void *d_signal, i
   a.in_f64 = signal_is_f64 != 0;
   a.dl_K = num_deltas;
   a.d_chunk_prefix = d_workspace;
+  a.prefix_prepared = workspace_prepared != 0;
   for (int j = 0; j < (num_deltas == 1 ? 5 : 14); ++j) a.dl_taps[j] = taps[j];
   return pds::launch_stft_fast_f32(plan, a);
 }
@@ -260,7 +261,56 @@ int32_t pds_stft_deltas_batch_f32(const pds_stft_plan *plan, const float *d_sign
                                   int32_t context_window, const double *taps, int64_t *d_workspace, float *d_out,
                                   int64_t out_stride, void *stream) {
   return pds_stft_deltas_batch(plan, d_signal, 0, d_offsets, d_lengths, d_nframes, d_row_off, B, max_frames, pad_left,
-                               0.0, num_deltas, context_window, taps, d_workspace, d_out, out_stride, stream);
+                               0.0, num_deltas, context_window, taps, d_workspace, 0, d_out, out_stride, stream);
+}
+
+int32_t pds_stft_plan_has_fused_cmvn(const pds_stft_plan *plan) { return plan && pds::fast_has_fused_cmvn(plan) ? 1 : 0; }
+
+int64_t pds_stft_cmvn_partials_len(const pds_stft_plan *plan, int32_t B) {
+  if (!plan || B < 0) return 0;
+  // one slot of [2][num_coeffs] float64 per (wave of the grid + utterance): at most 16 waves per CU
+  const int64_t waves = (int64_t)(plan->fast.num_cus > 0 ? plan->fast.num_cus : 256) * 16;
+  return (waves + B) * 2 * (int64_t)pds_stft_num_coeffs(plan);
+}
+
+int32_t pds_stft_prepare_chunk_prefix(const pds_stft_plan *plan, const int64_t *d_nframes, int32_t B,
+                                      int64_t *d_chunk_prefix, void *stream) {
+  if (!plan || !d_nframes || !d_chunk_prefix || B < 0) return invalid("stft_prepare_chunk_prefix: bad argument");
+  if (!plan->fast.kind || plan->fast.n2 <= 0) return invalid("stft_prepare_chunk_prefix: the plan has no fused kernel");
+  int32_t rc = pds::check_plan_device(plan->device, "stft_prepare_chunk_prefix");
+  if (rc != PDS_OK) return rc;
+  return pds::launch_chunk_prefix(d_nframes, B, 64 / plan->fast.n2, d_chunk_prefix, (hipStream_t)stream);
+}
+
+int32_t pds_stft_cmvn_batch_f32(const pds_stft_plan *plan, const float *d_signal, const int64_t *d_offsets,
+                                const int64_t *d_lengths, const int64_t *d_nframes, const int64_t *d_row_off, int32_t B,
+                                int64_t max_frames, int32_t pad_left, int32_t norm_var, int64_t *d_chunk_prefix,
+                                int32_t prefix_prepared, double *d_partials, int64_t partials_len, float *d_feats,
+                                int64_t feats_stride, double *d_stats, void *d_out, int32_t out_is_f64, int64_t out_stride,
+                                int32_t *d_zero_var, void *stream) {
+  int32_t rc = check_batch(plan, d_signal, d_offsets, d_lengths, d_nframes, d_row_off, B, max_frames, pad_left,
+                           d_feats, feats_stride);
+  if (rc == 1) return PDS_OK;
+  if (rc != PDS_OK) return rc;
+  if (!pds::fast_has_fused_cmvn(plan)) return invalid("stft_cmvn_batch: the plan has no fused CMVN sums");
+  const int32_t C = pds_stft_num_coeffs(plan);
+  if (!d_chunk_prefix || !d_partials || partials_len < pds_stft_cmvn_partials_len(plan, B))
+    return invalid("stft_cmvn_batch: chunk prefix or partial sums missing (pds_stft_cmvn_partials_len() float64)");
+  if (!d_stats || !d_out || out_stride < C) return invalid("stft_cmvn_batch: null output or out_stride < num_coeffs");
+  rc = pds::check_plan_device(plan->device, "stft_batch");
+  if (rc != PDS_OK) return rc;
+  int32_t grid_waves = 0;
+  pds::BatchArgs a{d_signal,   d_offsets, d_lengths,  d_nframes, d_row_off, B, max_frames,
+                   pad_left < 0 ? plan->d.pad_left : pad_left, 0.0, d_feats, feats_stride, (hipStream_t)stream};
+  a.stretch = true;
+  a.d_chunk_prefix = d_chunk_prefix;
+  a.prefix_prepared = prefix_prepared != 0;
+  a.d_stat_part = d_partials;
+  a.grid_waves_out = &grid_waves;
+  rc = pds::launch_stft_fast_f32(plan, a);
+  if (rc != PDS_OK) return rc;
+  return pds::launch_cmvn_rows_partials(d_feats, feats_stride, d_row_off, d_nframes, B, C, norm_var, d_chunk_prefix,
+                                        d_partials, grid_waves, d_stats, d_out, out_is_f64, out_stride, d_zero_var, stream);
 }
 
 }  // extern "C"

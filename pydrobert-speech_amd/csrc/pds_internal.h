@@ -133,6 +133,12 @@ struct BatchArgs {
   int64_t *d_chunk_prefix = nullptr;  // workspace of B + 1 entries (the utterances' chunk counts, summed)
   // ragged batches (pds_stft_batch_ragged_f32): stretch scheduling over the existing chunks, needs the workspace
   bool stretch = false;
+  // CMVN sums fused with the producer (pds_stft_cmvn_batch_f32; stretch launches): the pieces' float64 sums,
+  // [(grid waves + B)][2][num_coeffs], and where the launch reports its grid's waves
+  double *d_stat_part = nullptr;
+  int32_t *grid_waves_out = nullptr;
+  // d_chunk_prefix already holds the batch's chunk prefix sums (pds_stft_prepare_chunk_prefix): no kernel in front
+  bool prefix_prepared = false;
 };
 
 // stft_generic.hip
@@ -145,6 +151,14 @@ void fast_tables_destroy(pds_stft_plan *plan);
 int32_t launch_stft_fast_f32(const pds_stft_plan *plan, const BatchArgs &a);
 bool fast_has_f64in(const pds_stft_plan *plan);
 bool fast_has_fused_deltas(const pds_stft_plan *plan);
+bool fast_has_fused_cmvn(const pds_stft_plan *plan);
+// chunk_prefix[b] = chunks of `groups` frames in front of utterance b, [B] = all of them (stft_fast.hip)
+int32_t launch_chunk_prefix(const int64_t *d_nframes, int B, int groups, int64_t *d_prefix, hipStream_t stream);
+// post.hip: per-utterance CMVN whose sums the STFT launch left as per-piece partials (pds_stft_cmvn_batch_f32)
+int32_t launch_cmvn_rows_partials(const float *d_in, int64_t in_stride, const int64_t *d_row_off, const int64_t *d_nrows,
+                                  int32_t B, int32_t C, int32_t norm_var, const int64_t *d_chunk_prefix,
+                                  const double *d_partials, int32_t grid_waves, double *d_stats, void *d_out,
+                                  int32_t out_is_f64, int64_t out_stride, int32_t *d_zero_var, void *stream);
 
 // Runs `body` (plan construction: host allocations) so that no C++ exception crosses the C ABI.
 template <typename F>

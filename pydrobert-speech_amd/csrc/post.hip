@@ -343,6 +343,9 @@ static int32_t launch_cmvn_apply(const T *d_in, int64_t outer, int64_t C, int64_
 // (a 10 s utterance is only 1000 rows, so the latency of a load is what has to be covered),
 // pass 2 normalises (the rows are re-read from L2)
 constexpr int kRowPhases = 16;
+#ifndef PDS_CMVN_APPLY_DEPTH  // row loads in flight per thread in the normalising pass of cmvn_rows_partials_kernel
+#define PDS_CMVN_APPLY_DEPTH 8
+#endif
 template <typename OutT>
 __global__ __launch_bounds__(kRowPhases * 64) void cmvn_rows_kernel(
     const float *__restrict__ in, int64_t in_stride, const int64_t *__restrict__ row_off,
@@ -434,6 +437,91 @@ static int32_t launch_cmvn_rows(const float *d_in, int64_t in_stride, const int6
   hipLaunchKernelGGL(cmvn_rows_kernel<OutT>, dim3((unsigned)((C + 63) / 64), (unsigned)B),
                      dim3(kRowPhases * 64), 0, (hipStream_t)stream, d_in, in_stride, d_row_off,
                      d_nrows, C, norm_var, d_stats, d_out, out_stride, d_zero_var);
+  PDS_HIP(hipGetLastError());
+  return PDS_OK;
+}
+
+// The same normalisation with the sums taken by the STFT launch (pds_stft_cmvn_batch_f32: every wave walked one
+// contiguous stretch of the batch's chunks and left the float64 sums of each piece of an utterance at slot
+// (global wave + utterance) of `partials`): an utterance's pieces are the waves from the one holding its first
+// chunk to the one holding its last, added here in that order -- deterministic -- and the rows are read ONCE.
+template <typename OutT>
+__global__ __launch_bounds__(kRowPhases * 64) void cmvn_rows_partials_kernel(
+    const float *__restrict__ in, int64_t in_stride, const int64_t *__restrict__ row_off,
+    const int64_t *__restrict__ nrows, int C, int norm_var, const int64_t *__restrict__ prefix, int B,
+    const double *__restrict__ partials, int grid_waves, double *__restrict__ stats, OutT *__restrict__ out,
+    int64_t out_stride, int32_t *__restrict__ zero_var) {
+  constexpr int P = kRowPhases, U = PDS_CMVN_APPLY_DEPTH;
+  __shared__ double sc[64], sh[64];
+  const int b = blockIdx.y;
+  const int lane = threadIdx.x & 63, phase = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + lane;
+  const int64_t T = nrows[b];
+  if (T <= 0) return;
+  if (phase == 0 && c < C) {
+    // the stretch of chunks wave w walked: `per` chunks, one more for the first `rem` waves (stft_wave_kernel)
+    const int64_t total = prefix[B], first = prefix[b], last = prefix[b + 1] - 1;
+    const int64_t per = total / grid_waves, rem = total - per * grid_waves;
+    auto wave_of = [&](int64_t chunk) {
+      return chunk < rem * (per + 1) ? chunk / (per + 1) : rem + (chunk - rem * (per + 1)) / (per > 0 ? per : 1);
+    };
+    double s1 = 0.0, s2 = 0.0;
+    for (int64_t w = wave_of(first); w <= wave_of(last); ++w) {
+      const double *slot = partials + (w + b) * (2 * (int64_t)C);
+      s1 += slot[c];
+      s2 += slot[C + c];
+    }
+    stats[((int64_t)b * 2 + 0) * C + c] = s1;
+    stats[((int64_t)b * 2 + 1) * C + c] = s2;
+    const double mean = s1 / (double)T;
+    double scale = 1.0;
+    if (norm_var) {
+      double var = s2 / (double)T - mean * mean;
+      if (fabs(var) <= 1e-8) {  // numpy.isclose(var, 0) (post.py:283)
+        var = 1.0;
+        if (zero_var) atomicAdd(zero_var, 1);
+      }
+      scale = 1.0 / sqrt(var);
+    }
+    sc[lane] = scale;
+    sh[lane] = mean * scale;
+  }
+  __syncthreads();
+  if (c < C) {
+    const float *src = in + row_off[b] * in_stride + c;
+    OutT *dst = out + row_off[b] * out_stride + c;
+    const double scale = sc[lane], shift = sh[lane];
+    int64_t t = phase;
+    for (; t + (U - 1) * P < T; t += U * P) {
+      float v[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) v[u] = src[(t + u * P) * in_stride];
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+        dst[(t + u * P) * out_stride] = (OutT)__dsub_rn(__dmul_rn((double)v[u], scale), shift);
+    }
+    for (; t < T; t += P)
+      dst[t * out_stride] = (OutT)__dsub_rn(__dmul_rn((double)src[t * in_stride], scale), shift);
+  }
+}
+
+int32_t launch_cmvn_rows_partials(const float *d_in, int64_t in_stride, const int64_t *d_row_off, const int64_t *d_nrows,
+                                  int32_t B, int32_t C, int32_t norm_var, const int64_t *d_chunk_prefix,
+                                  const double *d_partials, int32_t grid_waves, double *d_stats, void *d_out,
+                                  int32_t out_is_f64, int64_t out_stride, int32_t *d_zero_var, void *stream) {
+  if (B <= 0 || C <= 0 || grid_waves <= 0) return invalid_post("cmvn_rows: bad B / coeff");
+  if (B > 65535) return invalid_post("cmvn_rows: B > 65535");
+  if (!d_in || !d_row_off || !d_nrows || !d_stats || !d_out || !d_chunk_prefix || !d_partials)
+    return invalid_post("cmvn_rows: null pointer");
+  const dim3 grid((unsigned)((C + 63) / 64), (unsigned)B), block(kRowPhases * 64);
+  if (out_is_f64)
+    hipLaunchKernelGGL(cmvn_rows_partials_kernel<double>, grid, block, 0, (hipStream_t)stream, d_in, in_stride, d_row_off,
+                       d_nrows, C, norm_var, d_chunk_prefix, B, d_partials, grid_waves, d_stats, (double *)d_out, out_stride,
+                       d_zero_var);
+  else
+    hipLaunchKernelGGL(cmvn_rows_partials_kernel<float>, grid, block, 0, (hipStream_t)stream, d_in, in_stride, d_row_off,
+                       d_nrows, C, norm_var, d_chunk_prefix, B, d_partials, grid_waves, d_stats, (float *)d_out, out_stride,
+                       d_zero_var);
   PDS_HIP(hipGetLastError());
   return PDS_OK;
 }

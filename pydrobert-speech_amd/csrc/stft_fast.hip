@@ -16,6 +16,14 @@ extern "C" __attribute__((visibility("default"))) int32_t pds_build_experiments(
 
 bool fast_has_f64in(const pds_stft_plan *plan) { return plan->fast.kind && fast_f64in_kind(plan->fast.kind); }
 
+// (fused CMVN sums: the 16-lane power-of-two geometries with a segment walk; whether the waves' sums fit in LDS
+// beside the walk's tables is decided at the launch, which refuses otherwise)
+bool fast_has_fused_cmvn(const pds_stft_plan *plan) {
+  const FastTables &ft = plan->fast;
+  // (the 128-register row-segment kernel of N = 512 does without: see STATS in the kernel)
+  return ft.kind && ft.n2 == 16 && ((ft.n1 == 64 && ft.walk != 0) || (ft.n1 == 32 && (ft.walk == 1 || ft.walk == 3)));
+}
+
 bool fast_has_fused_deltas(const pds_stft_plan *plan) {
   const FastTables &ft = plan->fast;
   return ft.kind && fast_deltas_kind(ft.kind) && ft.rsn_rounds >= 1 && ft.rsn_rounds <= 2 &&

@@ -193,6 +193,13 @@ struct FastParams {
   // fused statics + deltas launches (DLT instantiations): every wave walks ONE contiguous stretch of the
   // batch's chunks and keeps the statics of the last three chunks in registers (see the kernel)
   const int64_t *chunk_prefix;  // [num_utts + 1] chunks in front of every utterance (chunk_prefix_kernel)
+  // CMVN sums fused with the producer (STR launches, pds_stft_cmvn_batch_f32; reference post.py:250-295, SURVEY.md
+  // section 8 d): every wave adds the coefficients it stores to float64 sums in its own LDS slots, [2][stat_cs], and
+  // leaves them -- sum x, then sum x^2 -- at stat_part[(global wave + utterance) * 2 * stat_c] when its piece of an
+  // utterance ends; the normalising kernel adds an utterance's pieces in wave order (deterministic)
+  double *stat_part;
+  int stat_c, stat_cs;          // coefficients per row, and their count rounded up to a multiple of 4
+  int lds_stat_off;             // floats from the start of the workgroup's LDS to the waves' sums
   int dl_inner;                 // coefficients per frame (= num_coeffs): order k goes to columns [k C, (k + 1) C)
   int dl_order;                 // 1 or 2: orders of deltas appended (the DLT instantiation serves both)
   int dl_debug;                 // measurement switches (PDS_DL_DEBUG): 1 no delta stores, 2 no deltas at all, 4 no statics stores
@@ -401,6 +408,25 @@ __global__ __launch_bounds__(MAXWAVES * 64, MINW) void stft_wave_kernel(const Fa
   constexpr int LOADSPAN = PAIR ? (NROWS + 1) / 2 * 32 : NROWS * N2;  // samples a frame's direct loads reach over
   [[maybe_unused]] const unsigned long long st_entry = PDS_STAMPS ? __builtin_readcyclecounter() : 0;
   float *wbase = smem + wave * (G::EXCH_F2 * 2);
+  // (STR launches with fused CMVN sums: the wave's float64 sums, zero at the start of every piece)
+  [[maybe_unused]] double *wstat = reinterpret_cast<double *>(smem + p.lds_stat_off) + wave * (2 * p.stat_cs);
+  // (compiled into the stretch-scheduled kernels of the segment walks, and of the row-segment walk where the
+  // geometry has 256 registers: in the 128-register row-segment kernel the sums cost four spilled registers)
+  constexpr bool STATS = STR && G::GROUPS == 4 && (SEG != 0 || (RSG && MINW <= 2));
+  [[maybe_unused]] const bool stats_on = STATS && p.stat_part != nullptr;
+  // the coefficient `col` of the item's four frames (the first `nf` of them exist), held by ONE lane
+  [[maybe_unused]] auto stat_add4 = [&](const int col, const float (&v)[4], const int nf) {
+    double t1 = 0.0, t2 = 0.0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      if (q < nf) {
+        const double d = (double)v[q];
+        t1 += d;
+        t2 = fma(d, d, t2);
+      }
+    wstat[col] += t1;
+    wstat[p.stat_cs + col] += t2;
+  };
   float2 *exch = reinterpret_cast<float2 *>(wbase) + g * G::XROWS * RS;
   [[maybe_unused]] float *xf = wbase + g * (G::XROWS * G::RSF);  // LEAN: the frame's exchange block, one float per element
   float *Pg = wbase + g * PSTR;
@@ -440,6 +466,12 @@ __global__ __launch_bounds__(MAXWAVES * 64, MINW) void stft_wave_kernel(const Fa
   [[maybe_unused]] int *ticket_lds = reinterpret_cast<int *>(smem + p.lds_ticket_off);
   if constexpr (DYN) {
     if (threadIdx.x == 0) *ticket_lds = p.waves;  // (tickets 0 .. waves - 1 are the waves' first items)
+  }
+  if constexpr (STR && G::GROUPS == 4 && (SEG != 0 || (RSG && MINW <= 2))) {
+    if (p.stat_part) {
+      double *z = reinterpret_cast<double *>(smem + p.lds_stat_off);
+      for (int i = threadIdx.x; i < p.waves * 2 * p.stat_cs; i += p.waves * 64) z[i] = 0.0;
+    }
   }
   // (slots beyond the table read as "no filter": the unrolled slot loop fetches USLOTS entries)
   for (int i = threadIdx.x; i < p.ell_meta_pad; i += nthreads)
@@ -764,6 +796,20 @@ __global__ __launch_bounds__(MAXWAVES * 64, MINW) void stft_wave_kernel(const Fa
 #pragma unroll
             for (int q = 0; q < 4; ++q) nx[rd][q] = Wc[rd][3];
           emit_rows(c_last, nx);
+        }
+        if constexpr (STATS) {
+          if (stats_on) {
+            // the piece's sums: slot (global wave + utterance) -- pieces in chunk order differ in one of the two
+            wave_sync();
+            double *dst = p.stat_part + ((int64_t)(wg * p.waves + wave) + b) * (2 * p.stat_c);
+            for (int c = lane; c < p.stat_c; c += 64) {
+              dst[c] = wstat[c];
+              dst[p.stat_c + c] = wstat[p.stat_cs + c];
+              wstat[c] = 0.0;
+              wstat[p.stat_cs + c] = 0.0;
+            }
+            wave_sync();
+          }
         }
         left -= e_hi - e_lo;
         ++b;
@@ -1522,6 +1568,15 @@ __global__ __launch_bounds__(MAXWAVES * 64, MINW) void stft_wave_kernel(const Fa
       if (p.use_log) e = fast_log(p.log_floor > e ? p.log_floor : e);
       if (DLT == 0 && valid && r == 0) obase[lane_off - col0] = (TOUT)e;
       if constexpr (DLT > 0) e_keep = e;
+      if constexpr (STATS) {
+        if (stats_on) {
+          const float e4[4] = {__int_as_float(__builtin_amdgcn_readlane(__float_as_int(e), 0)),
+                               __int_as_float(__builtin_amdgcn_readlane(__float_as_int(e), 16)),
+                               __int_as_float(__builtin_amdgcn_readlane(__float_as_int(e), 32)),
+                               __int_as_float(__builtin_amdgcn_readlane(__float_as_int(e), 48))};
+          if (lane == 0) stat_add4(0, e4, nfr - tb);
+        }
+      }
     }
     PDS_STAMP(4, 0);  // P stores, energy
     PDS_PHASE(3);
@@ -1686,6 +1741,9 @@ __global__ __launch_bounds__(MAXWAVES * 64, MINW) void stft_wave_kernel(const Fa
           if (p.use_log) v = fast_log(p.log_floor > v ? p.log_floor : v);
           if (DLT == 0 && f >= 0 && gg < frames_here) dst[(int64_t)gg * p.out_stride] = (TOUT)v;
           logged[gg] = v;
+        }
+        if constexpr (STATS) {
+          if (stats_on && f >= 0) stat_add4(col0 + f, logged, frames_here);
         }
       };
       if constexpr (DLT == 0) {
@@ -1905,6 +1963,10 @@ __global__ __launch_bounds__(MAXWAVES * 64, MINW) void stft_wave_kernel(const Fa
             // max(val, floor) as Python evaluates it: a NaN stays a NaN (compute.py:459)
             if (p.use_log) v = fast_log(p.log_floor > v ? p.log_floor : v);
             if (gg < frames_here) obase[(int64_t)gg * p.out_stride + col0 + f] = (TOUT)v;
+            sum[gg] = v;
+          }
+          if constexpr (STATS) {
+            if (stats_on) stat_add4(col0 + f, sum, frames_here);
           }
         }
         PDS_STAMP(5, 0);  // filter walk
@@ -1941,8 +2003,6 @@ constexpr bool fast_f64in_kind(int n) { return n == 256 || n == 512 || n == 1024
 // transform sizes with fused statics + deltas instantiations (16-lane geometries)
 constexpr bool fast_deltas_kind(int n) { return n == 512 || n == 1024; }
 
-// stft_fast.hip: chunk_prefix[b] = chunks of `groups` frames in front of utterance b, [B] = all of them
-int32_t launch_chunk_prefix(const int64_t *d_nframes, int B, int groups, int64_t *d_prefix, hipStream_t stream);
 
 template <int N1, int N2, int NROWS, int MINW>
 int32_t launch_wave(const pds_stft_plan *plan, const BatchArgs &a) {
@@ -1999,6 +2059,10 @@ int32_t launch_wave(const pds_stft_plan *plan, const BatchArgs &a) {
   // stay in global memory.
   const size_t lds_cu = 160 * 1024;
   const size_t per_wave = (size_t)G::EXCH_F2 * 8;
+  // fused CMVN sums (pds_stft_cmvn_batch_f32): [2][coefficients rounded up to 4] float64 per wave, in LDS
+  const int stat_c = a.d_stat_part ? plan->d.num_filts + (plan->d.include_energy ? 1 : 0) : 0;
+  const int stat_cs = (stat_c + 3) & ~3;
+  const size_t stat_pw = (size_t)2 * stat_cs * 8;
   int shapes[4][2] = {{CU_WAVES / 2, 2}, {CU_WAVES, 1}, {CU_WAVES * 3 / 4, 1}, {CU_WAVES * 5 / 8, 1}};
 #ifdef PDS_ONE_WG  // (experiment: one workgroup per CU whatever fits)
   shapes[0][0] = CU_WAVES, shapes[0][1] = 1;
@@ -2047,7 +2111,7 @@ int32_t launch_wave(const pds_stft_plan *plan, const BatchArgs &a) {
     if (cand == 1 && (size_t)G::GROUPS * G::PSTR * 4 + (size_t)ft.seg_rounds * 64 * 4 * G::GROUPS > per_wave) continue;
     if (cand == 3 && (size_t)G::GROUPS * G::PSTR * 4 + (size_t)ft.ms_rounds * 64 * 16 > per_wave) continue;
     for (const auto &shape : shapes)
-      if (shape[0] * per_wave + fixed + table_bytes + 32 <= lds_cu / shape[1]) {  // (+ the ticket counter)
+      if (shape[0] * (per_wave + stat_pw) + fixed + table_bytes + 48 <= lds_cu / shape[1]) {  // (+ the ticket counter)
         waves = shape[0];
         wgs_per_cu = shape[1];
         in_lds = true;
@@ -2097,6 +2161,11 @@ int32_t launch_wave(const pds_stft_plan *plan, const BatchArgs &a) {
   smem = (smem + 15) & ~(size_t)15;
   p.lds_ticket_off = (int)(smem / 4);  // the workgroup's ticket counter
   smem += 16;
+  p.lds_stat_off = (int)(smem / 4);    // the waves' CMVN sums
+  smem += (size_t)waves * stat_pw;
+  p.stat_part = nullptr;
+  p.stat_c = stat_c;
+  p.stat_cs = stat_cs;
   p.waves_rcp = (unsigned)((0x100000000ull + (unsigned)waves - 1) / (unsigned)waves);
   {
     const char *dyn_env = std::getenv("PDS_STFT_DYN");
@@ -2150,6 +2219,16 @@ int32_t launch_wave(const pds_stft_plan *plan, const BatchArgs &a) {
            : in_lds ? stft_wave_kernel<N1, N2, NROWS, CU_WAVES_K, MINW, true, false, 0, 0, false, float, float, 0, true>
                     : stft_wave_kernel<N1, N2, NROWS, CU_WAVES_K, MINW, false, false, 0, 0, false, float, float, 0, true>;
     p.chunk_prefix = a.d_chunk_prefix;
+  }
+  if (a.d_stat_part) {
+    // (the sums are taken where ONE lane holds a coefficient of the item's four frames: the row-segment, segmented
+    // and matrix-pipe walks of the 16-lane geometries, tables in LDS)
+    if (!str_used || !in_lds || walk == 0 || G::GROUPS != 4 || (rsg && MINW > 2)) {
+      set_error("stft_cmvn_batch: not served for this plan and call (needs a 16-lane power-of-two geometry, a segment "
+                "walk with its tables and the waves' sums in LDS, float32 samples, no fused pre-emphasis)");
+      return PDS_ERR_INVALID;
+    }
+    p.stat_part = a.d_stat_part;
   }
   // float64 samples (pds_stft_batch_f64in): the common power-of-two geometries, LDS-resident tables,
   // ELL or row-segment walk; float64 features without fused pre-emphasis only
@@ -2246,11 +2325,12 @@ int32_t launch_wave(const pds_stft_plan *plan, const BatchArgs &a) {
   if (a.dl_K > 0 || str_used) {
     // the utterances' chunk counts summed up on the device, then one stretch of chunks per wave
     grid = std::min<int64_t>((int64_t)ft.num_cus * wgs_per_cu, std::max<int64_t>(1, (chunks * a.B + 4 * waves - 1) / (4 * waves)));
-    {
+    if (!a.prefix_prepared) {
       const int32_t rc_prefix = launch_chunk_prefix(a.d_nframes, a.B, G::GROUPS, a.d_chunk_prefix, a.stream);
       if (rc_prefix != PDS_OK) return rc_prefix;
     }
   }
+  if (a.grid_waves_out) *a.grid_waves_out = (int32_t)(grid * waves);
   hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(waves * 64), smem, a.stream, p);
   PDS_HIP(hipGetLastError());
   return PDS_OK;

@@ -554,3 +554,67 @@ def test_launch_with_deltas_float64_arithmetic_falls_back_to_float64_statics():
     ref[:, :C] = got[:, :C]
     d.apply_rows(ref[:, :C], layout.row_offsets, out=ref)
     assert torch.equal(got, ref)
+
+
+@pytest.mark.parametrize("bank", ["gammatone64_48k", "gabor64", "fbank80_energy", "mel40"])
+@pytest.mark.parametrize("out_dtype", ["f8", "f4"])
+def test_cmvn_sums_fused_with_the_stft_launch(bank, out_dtype):
+    """pds_stft_cmvn_batch_f32 (the STFT launch adds what it stores to per-wave float64 sums; the normalising kernel
+    adds an utterance's pieces in wave order and reads the features once) against launch + CMVN.apply_rows and the
+    oracle, on ragged batches with empty, one-frame and long utterances; features bit for bit, sums to 1e-12
+    relative, standardised features to the CMVN tolerance; the same call twice gives the same bits"""
+    import torch
+
+    from oracle import stft_oracle as orc
+    from pydrobert_speech_amd.alias import alias_factory_subclass_from_arg
+    from pydrobert_speech_amd.compute import FrameComputer
+    from pydrobert_speech_amd.post import CMVN
+
+    cfg = {
+        "gammatone64_48k": {"name": "stft", "bank": {"name": "gammatone", "scaling_function": "mel", "num_filts": 64,
+                                                     "sampling_rate": 48000}, "frame_length_ms": 20, "use_power": True},
+        "gabor64": {"name": "stft", "bank": {"name": "gabor", "scaling_function": "mel", "num_filts": 64},
+                    "frame_length_ms": 25, "use_power": True},
+        "fbank80_energy": {"name": "stft", "bank": {"name": "fbank", "num_filts": 80}, "frame_length_ms": 25,
+                           "include_energy": True, "use_power": True},
+        "mel40": {"name": "stft", "bank": {"name": "tri", "scaling_function": "mel", "num_filts": 40},
+                  "frame_length_ms": 25, "frame_shift_ms": 10, "use_power": True},
+    }[bank]
+    comp = alias_factory_subclass_from_arg(FrameComputer, cfg)
+    plan = comp._native_plan()
+    # (the dense banks' segment walks carry the sums; the 128-register row-segment kernel of the mel banks at N = 512
+    # does not: launch_with_cmvn then makes the two calls, and the same checks hold)
+    assert plan.has_fused_cmvn == (bank in ("gammatone64_48k", "gabor64"))
+    tdt = torch.float64 if out_dtype == "f8" else torch.float32
+    rng = np.random.default_rng(11)
+    S, C = comp.frame_shift, comp.num_coeffs
+
+    def check(lens, what):
+        x = torch.from_numpy((3000 * rng.standard_normal(int(np.sum(lens)))).astype("f4")).cuda()
+        offs = np.concatenate([[0], np.cumsum(lens)[:-1]])
+        layout = comp.prepare_layout(offs, lens, device=x.device)
+        feats = torch.full((layout.total_rows, C), float("nan"), device="cuda")
+        fused = comp.launch_with_cmvn(x, layout, CMVN(), feats_out=feats, out_dtype=tdt, fused=True)
+        again = comp.launch_with_cmvn(x, layout, CMVN(), out_dtype=tdt, fused=True)
+        plain = comp.launch(x, layout)
+        two = CMVN().apply_rows(plain, layout.row_offsets, out_dtype=tdt)
+        assert fused.dtype == tdt and fused.shape == two.shape == (layout.total_rows, C), what
+        assert bool(torch.isfinite(fused).all()), what
+        assert torch.equal(fused, again), what  # deterministic: pieces are added in a fixed order
+        # the features themselves: the stretch-scheduled launch of the same kernel
+        assert torch.equal(feats, plain) or float((feats - plain).abs().max()) <= 2e-6 * float(plain.abs().max()), what
+        tol = 1e-9 if out_dtype == "f8" else 2e-6
+        err = (fused.double() - two.double()).abs().max().item() if fused.numel() else 0.0
+        assert err <= tol * max(1.0, float(two.abs().max()) if two.numel() else 1.0), (what, err)
+        return layout, feats, fused
+
+    lens = [0, S, 5 * S, 9 * S + 3, 100000, 33 * S, 1, 4 * S, 57000, 12 * S, 100 * S + 7, 8 * S, 2 * S]
+    layout, feats, fused = check(lens, "ragged")
+    host, got = feats.cpu().numpy(), fused.cpu().numpy()
+    for b in (2, 4, 10):
+        rows = slice(layout.row_offsets[b], layout.row_offsets[b + 1])
+        want = orc.cmvn_local(host[rows], axis=-1)
+        assert np.allclose(got[rows], want, rtol=1e-8 if out_dtype == "f8" else 1e-5, atol=1e-8 if out_dtype == "f8" else 2e-5)
+    check(rng.integers(0, 40 * S, size=700), "many short")
+    check([700 * S + 5, 0, 333 * S, 1000 * S], "few long")
+    check([50 * S] * 64, "equal")
