@@ -11,6 +11,7 @@ tests/test_resources.py fails when a default-path instantiation (a kernel the pl
 """
 import os
 import re
+import signal
 import struct
 import subprocess
 import sys
@@ -88,6 +89,7 @@ def short(name):
 
 
 def main():
+    signal.signal(signal.SIGPIPE, signal.SIG_DFL)  # (| head)
     args = [a for a in sys.argv[1:] if not a.startswith("--")]
     lib = args[0] if args else os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
                                             "pydrobert-speech_amd", "csrc", "libpds_amd.so")
