@@ -589,8 +589,8 @@ class ShortTimeFourierTransformFrameComputer(LinearFilterBankFrameComputer):
                         int(layout.nframes[lo:hi].max()), pad, float(preemphasis), K, 2, taps.ctypes.data,
                         work.data_ptr(), int(single), out.data_ptr(), out.stride(0), stream,
                     )
-                    if rc != 0 and lo == 0:
-                        fused = False  # (e.g. a filter table that does not fit in LDS): the two launches below
+                    if rc == -1 and lo == 0:
+                        fused = False  # (not served, e.g. a filter table that does not fit in LDS): the two launches below
                         break
                     _native.check(rc, "pds_stft_deltas_batch")
         if not fused:
@@ -664,7 +664,8 @@ class ShortTimeFourierTransformFrameComputer(LinearFilterBankFrameComputer):
             if rc == 0:
                 cmvn._last_zero_var = zero_var
                 return out[:total, :C] if out.shape != (total, C) else out
-            # (e.g. no room in LDS for the waves' sums beside the filter table): the two calls below
+            if rc != -1:  # (PDS_ERR_INVALID = not served, e.g. no room in LDS for the waves' sums: the two calls below)
+                _native.check(rc, "pds_stft_cmvn_batch")
         if feats_out is not None and signal.dtype == torch.float32:
             feats = self.launch(signal, layout, pad_left=pad_left, out=feats_out)[:total, :C]
         else:

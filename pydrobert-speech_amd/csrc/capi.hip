@@ -297,6 +297,7 @@ int32_t pds_stft_cmvn_batch_f32(const pds_stft_plan *plan, const float *d_signal
   if (!d_chunk_prefix || !d_partials || partials_len < pds_stft_cmvn_partials_len(plan, B))
     return invalid("stft_cmvn_batch: chunk prefix or partial sums missing (pds_stft_cmvn_partials_len() float64)");
   if (!d_stats || !d_out || out_stride < C) return invalid("stft_cmvn_batch: null output or out_stride < num_coeffs");
+  if (B > 65535) return invalid("stft_cmvn_batch: B > 65535");
   rc = pds::check_plan_device(plan->device, "stft_batch");
   if (rc != PDS_OK) return rc;
   int32_t grid_waves = 0;
