@@ -151,7 +151,7 @@ extern unsigned long long *g_stamp_buf;  // (stft_fast.hip: pds_debug_set_stamp_
 #define PDS_PF_WIN 0
 #endif
 #ifndef PDS_PF_PLACE
-#define PDS_PF_PLACE 0
+#define PDS_PF_PLACE 1
 #endif
 #ifndef PDS_PF_WINAT  // (WINLDS: the window slice is re-read 0 inside a walk round, behind its reads, 1 behind the rounds)
 #define PDS_PF_WINAT 1
@@ -356,8 +356,8 @@ __global__ __launch_bounds__(MAXWAVES * 64, MINW) void stft_wave_kernel(const Fa
   // three seeds W^r, W^4r, W^8r and regenerates W^(r k1), k1 = 1..15, per item by twelve complex products at
   // most four deep (twiddle_chain; tests/test_twiddle_chain.py replays it against float64).  The next item's
   // utterance record is fetched at the top of the item for that.
-  static_assert(!PF || (DLT == 0 && !STR && MF == 0 && !PRE && std::is_same<TIN, float>::value && N1 == 32 && N2 == 16),
-                "prefetch: 32 x 16 geometry, float32 samples, round-robin scheduling");
+  static_assert(!PF || (DLT == 0 && !STR && MF == 0 && !PRE && std::is_same<TIN, float>::value && (N1 == 32 || N1 == 64) && N2 == 16),
+                "prefetch: 16-lane power-of-two geometries, float32 samples, round-robin scheduling");
   // STR: the stretch scheduling of the DLT launches without their deltas -- every wave walks one contiguous
   // stretch of the batch's EXISTING chunks (chunk_prefix) -- for ragged batches: dealt round-robin over
   // (utterance, chunk < chunks of the longest) the waves skip the chunks short utterances do not have and end
@@ -441,7 +441,8 @@ __global__ __launch_bounds__(MAXWAVES * 64, MINW) void stft_wave_kernel(const Fa
   // instantiations of the 16-lane geometries, whose 16-byte pair loads keep 4 registers per pair in flight (52 at 25
   // rows: with thirty registers of twiddles beside them the kernel spilled 10 ... 34 registers), and the prefetch
   // experiment
-  constexpr bool TWCHAIN = (PF && PDS_PF_TW == 1) || (PAIR && (N1 == 32 || N1 == 64)) || (PDS_DLT_CHAIN && DLT > 0 && N1 == 32 && N2 == 16) || G::LEAN;
+  constexpr bool TWCHAIN = (PF && PDS_PF_TW == 1) || (PAIR && (N1 == 32 || N1 == 64)) || (PDS_DLT_CHAIN && DLT > 0 && N1 == 32 && N2 == 16) || G::LEAN ||
+                           (N1 == 64 && N2 == 16 && SEG == 2);  // (the matrix-pipe walk's launches at N = 1024: the plain one prefetches, and the ragged one must give the same bits)
   constexpr bool WINLDS = PF && PDS_PF_WIN == 1;  // window slice re-read from LDS per item (in front of the item: prefetch experiment)
   constexpr bool WINUSE = G::LEAN;                // ... read from LDS where it is applied
   constexpr int WSTR = win_table_stride(NROWS);
@@ -2090,10 +2091,15 @@ int32_t launch_wave(const pds_stft_plan *plan, const BatchArgs &a) {
   const bool dl = a.dl_K > 0 && ft.rsn_rounds > 0;  // (its own table: numbered order)
   // prefetch instantiation (PF): 32 x 16 geometry with the row-segment walk, float32 samples, round-robin
   // scheduling (PDS_STFT_PF=0 keeps the kernel without it)
-  constexpr bool PFG = N1 == 32 && N2 == 16;
+  constexpr bool PFG = (N1 == 32 || N1 == 64) && N2 == 16;
   const char *pf_env = std::getenv("PDS_STFT_PF");
-  const bool pf_ok = PDS_EXPERIMENTS && PFG && !pre && !a.in_f64 && !a.stretch && a.dl_K == 0 && ft.d_win_half &&
-                     ft.d_tw_seed && !(pf_env && pf_env[0] == '0');
+  // (product build: the N = 1024 geometry's matrix-pipe walk -- configs[4], which waits for its loads at two waves per
+  // SIMD and is not bound by the vector pipe: +2.7 %, profiles/r3j_prefetch_n1024_ab.txt; the 128-register geometry
+  // and the other walks, where it measured -4 % / +-0, with -DPDS_EXPERIMENTS=1 only)
+  constexpr bool PF_PRODUCT = N1 == 64 && N2 == 16;
+  constexpr bool PF_MSEG = PF_PRODUCT && G::GROUPS == 4 && inl::is_pow2(N1);  // (the plain matrix-pipe launch IS the prefetch form)
+  const bool pf_ok = (PDS_EXPERIMENTS || PF_PRODUCT) && PFG && !pre && !a.in_f64 && !a.stretch && a.dl_K == 0 &&
+                     ft.d_win_half && ft.d_tw_seed && !(pf_env && pf_env[0] == '0');
   constexpr int PF_WSTR = ((NROWS + 3) & ~3) % 8 == 4 ? ((NROWS + 3) & ~3) : ((NROWS + 3) & ~3) + 4;
   const size_t pf_extra = (PDS_PF_WIN == 1) ? (size_t)N2 * PF_WSTR * 4 : 0;  // window table in LDS
   const size_t lean_extra = G::LEAN ? (size_t)N2 * win_table_stride(NROWS) * 4 : 0;  // ... of the lean geometries
@@ -2176,7 +2182,7 @@ int32_t launch_wave(const pds_stft_plan *plan, const BatchArgs &a) {
   auto kern = pre      ? (rsg ? stft_wave_kernel<N1, N2, NROWS, CU_WAVES_K, MINW, true, true, false, 0, W4>
                               : stft_wave_kernel<N1, N2, NROWS, CU_WAVES_K, MINW, true, true>)
               : rsg    ? stft_wave_kernel<N1, N2, NROWS, CU_WAVES_K, MINW, true, false, false, 0, W4>
-              : mseg   ? stft_wave_kernel<N1, N2, NROWS, CU_WAVES_K, MINW, true, false, MSG ? 2 : 0>
+              : mseg   ? stft_wave_kernel<N1, N2, NROWS, CU_WAVES_K, MINW, true, false, MSG ? 2 : 0, 0, false, float, float, 0, false, PF_MSEG>
               : seg    ? stft_wave_kernel<N1, N2, NROWS, CU_WAVES_K, MINW, true, false, SEGOK ? 1 : 0>
               : in_lds ? stft_wave_kernel<N1, N2, NROWS, CU_WAVES_K, MINW, true, false>
                        : stft_wave_kernel<N1, N2, NROWS, CU_WAVES_K, MINW, false, false>;
@@ -2196,11 +2202,17 @@ int32_t launch_wave(const pds_stft_plan *plan, const BatchArgs &a) {
     }
   }
   bool pf_used = false;
+  if (PF_MSEG && mseg && !pre) {
+    p.win_half = ft.d_win_half;  // (regenerated twiddles: see the kernel)
+    p.tw_seed = (const float2 *)ft.d_tw_seed;
+  }
 #if PDS_EXPERIMENTS
   if constexpr (PFG) {
-    if (pf_ok && rsg && in_lds && !mf) {
+    if (pf_ok && in_lds && !mf && (rsg || seg || (mseg && !PF_MSEG))) {
       pf_used = true;
-      kern = stft_wave_kernel<N1, N2, NROWS, CU_WAVES_K, MINW, true, false, 0, 0, W4, float, float, 0, false, PFG>;
+      kern = rsg    ? stft_wave_kernel<N1, N2, NROWS, CU_WAVES_K, MINW, true, false, 0, 0, W4, float, float, 0, false, PFG>
+             : mseg ? stft_wave_kernel<N1, N2, NROWS, CU_WAVES_K, MINW, true, false, MSG ? 2 : 0, 0, false, float, float, 0, false, PFG>
+                    : stft_wave_kernel<N1, N2, NROWS, CU_WAVES_K, MINW, true, false, SEGOK ? 1 : 0, 0, false, float, float, 0, false, PFG>;
       p.win_half = ft.d_win_half;
       p.tw_seed = (const float2 *)ft.d_tw_seed;
     }
@@ -2306,7 +2318,7 @@ int32_t launch_wave(const pds_stft_plan *plan, const BatchArgs &a) {
   static std::atomic<size_t> attr_smem[kDevices][32];
   const int which = dl_which >= 0    ? dl_which
                     : f64_which >= 0 ? f64_which
-                    : pf_used        ? 27
+                    : pf_used        ? (rsg ? 27 : mseg ? 30 : 31)
                     : str_used       ? 22 + (rsg ? 0 : mseg ? 1 : seg ? 2 : in_lds ? 3 : 4)
                     : mseg           ? 20
                                      : (pre ? (rsg ? 5 : 2) : rsg ? 4 : seg ? 3 : (in_lds ? 1 : 0)) + (mf ? 6 : 0);
