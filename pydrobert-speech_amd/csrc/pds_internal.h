@@ -51,8 +51,8 @@ struct FastTables {
   int rs_eslot = -1;               // round * 64 + lane of a lane that finishes no filter (-1: every lane does)
   // matrix-pipe segment walk (mseg_tables.h; 16-lane power-of-two geometries, dense banks): 0 rounds = not built
   float *d_ms_w = nullptr;         // [ms_rounds][ms_len / 4][64][4]
-  int32_t *d_ms_meta = nullptr;    // [ms_rounds * 16] unit first bins, then [num_filts] first partial slot | units << 16
-  int ms_rounds = 0, ms_len = 0, ms_wfloats = 0, ms_meta_ints = 0;
+  int32_t *d_ms_meta = nullptr;    // [ms_rounds * 16] first bin | flush << 15 | slot << 16, then [num_filts] first partial entry | slots << 16
+  int ms_rounds = 0, ms_len = 0, ms_wfloats = 0, ms_meta_ints = 0, ms_slots = 0;
   long ms_reads = 0;
   int walk = 0;  // preferred filter walk: 0 ELL, 1 segments (dense banks), 2 row segments, 3 matrix-pipe segments
   long rs_reads = 0, rs_cost = 0, ell_reads = 0, seg_reads = 0;  // 16-byte LDS reads per lane and item of each walk

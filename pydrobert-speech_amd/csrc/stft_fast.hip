@@ -230,24 +230,28 @@ int32_t fast_tables_create(pds_stft_plan *plan, const double *window, const int3
   // filter of an 80-filter mel bank at N = 4096 while the lanes of short filters idle -- and segments of
   // equal length dealt to all 64 lanes need fewer reads in fewer dependent steps.)
   const int groups = 64 / n2;  // frames per wave
+  bool dense_bank = false;  // the bank is one a segment walk pays for (whether or not the plain one fits the wave's area)
+  long dense_reads = 0;     // ... and the 16-byte LDS reads per item the plain segment walk would need for it
   if ((n2 == 16 || (pow2 && n2 >= 32)) && d.num_filts > 0 && d.num_filts <= 65535) {
     long ell_reads = 0;
     for (int sl = 0; sl < slots; ++sl) ell_reads += 2L * (ell_len[sl] / 4);  // per lane and item
     ft.ell_reads = ell_reads;
     const int free_slots = (wave_area_floats(n1, n2) - groups * pstr) / groups;  // partial slots behind P
     int best_len = 0, best_rounds = 0;
-    long best_reads = 0;
+    long best_reads = 0, any_reads = 0;  // (any_reads: the fewest reads of a segment length whether or not its sums fit)
     const char *only_len = std::getenv("PDS_SEG_LEN");  // (measurement: one segment length)
     for (int len : {16, 32, 64}) {
       if (only_len && std::atoi(only_len) != len) continue;
       long nseg = 0;
       for (int f = 0; f < d.num_filts; ++f) nseg += (span(f) + len - 1) / len;
       const int rounds = (int)((nseg + 63) / 64);
-      if (rounds == 0 || rounds * 64 > free_slots || rounds * 64 > 65535) continue;
+      if (rounds == 0 || rounds * 64 > 65535) continue;
       int longest = 0;
       for (int f = 0; f < d.num_filts; ++f) longest = std::max(longest, (span(f) + len - 1) / len);
       // (reads of the rounds, their epilogues, and the partial sums a filter's lane adds up four at a time)
       const long reads = (long)rounds * (len / 4) * (1 + groups) + rounds + (nseg + 63) / 64 + 4 + 4L * ((longest + 3) / 4);
+      if (!any_reads || reads < any_reads) any_reads = reads;
+      if (rounds * 64 > free_slots) continue;
       if (!best_len || reads < best_reads) best_len = len, best_rounds = rounds, best_reads = reads;
     }
     const char *force = std::getenv("PDS_STFT_SEGMENTED");  // "1": whenever feasible, "0": never
@@ -257,10 +261,15 @@ int32_t fast_tables_create(pds_stft_plan *plan, const double *window, const int3
     // with four and more ELL slots their per-slot epilogues (log, scattered stores) weigh in as well
     // (80 mel filters at 48 kHz: N = 4096, one frame per wave, 54 reads against 96: +18 %; N = 2048, two frames
     // per wave, 46 against 60: -6 %, so the 32-lane geometries take it only when forced)
-    const bool want = force    ? force[0] == '1'
-                      : n2 == 64 ? best_reads < ell_reads
-                      : n2 == 32 ? 10 * best_reads <= 7 * ell_reads  // (dense banks; the mel bank above: 46 against 60)
-                                 : 5 * best_reads <= 4 * ell_reads || (slots >= 4 && best_reads < ell_reads);
+    auto wanted = [&](long reads) {
+      return force      ? force[0] == '1'
+             : n2 == 64 ? reads < ell_reads
+             : n2 == 32 ? 10 * reads <= 7 * ell_reads  // (dense banks; the mel bank above: 46 against 60)
+                        : 5 * reads <= 4 * ell_reads || (slots >= 4 && reads < ell_reads);
+    };
+    const bool want = wanted(best_reads);
+    dense_bank = any_reads > 0 && wanted(any_reads);
+    dense_reads = any_reads;
     if (best_len && want) {
       const int len = best_len, nslots = best_rounds * 64, wstride = len + 4;
       std::vector<float> seg_w((size_t)nslots * wstride, 0.0f);
@@ -324,12 +333,13 @@ int32_t fast_tables_create(pds_stft_plan *plan, const double *window, const int3
   }
   // Matrix-pipe segment walk (mseg_tables.h): built where the segmented walk is (dense banks), for the
   // power-of-two 16-lane geometries
-  if (n2 == 16 && pow2 && rc == PDS_OK && ft.seg_rounds > 0) {
+  if (n2 == 16 && pow2 && rc == PDS_OK && dense_bank) {
     MsegTables ms;
     const int area_floats = wave_area_floats(n1, n2);  // WaveGeom::EXCH_F2 * 2
-    const int max_units = (area_floats - 4 * pstr) / 16;  // four float4 partial slots per unit behind P
-    if (build_mseg(d.num_filts, row_ptr, col, val, pstr, max_units, ms)) {
+    const int max_slots = (area_floats - 4 * pstr) / 16;  // partial-sum slots (four float4 each) behind P
+    if (build_mseg(d.num_filts, row_ptr, col, val, pstr, max_slots, ms)) {
       ft.ms_rounds = ms.rounds;
+      ft.ms_slots = ms.slots;
       ft.ms_len = ms.seg_len;
       ft.ms_wfloats = (int)ms.w.size();
       ft.ms_meta_ints = (int)ms.meta.size();
@@ -341,7 +351,10 @@ int32_t fast_tables_create(pds_stft_plan *plan, const double *window, const int3
   {
     const char *force = std::getenv("PDS_STFT_WALK");
     ft.walk = ft.seg_rounds > 0 ? 1 : 0;  // (the segmented walk's own criterion, above)
-    const long other = ft.walk == 1 ? ft.seg_reads : ft.ell_reads;
+    // (a dense bank whose plain segment walk does not fit the wave's area still competes with that walk's read
+    // count: the matrix-pipe form below stands in for it)
+    const bool ms_stands_in = ft.walk == 0 && dense_bank && ft.ms_rounds > 0 && N >= PDS_MSEG_MIN_N;
+    const long other = ft.walk == 1 ? ft.seg_reads : ms_stands_in ? dense_reads : ft.ell_reads;
     // (measured: 40 mel filters, 15 reads in one round against 32: +5 %; 80 mel filters, 20 in two rounds
     // against 32: +2 %; Gabor-64, 45 in three rounds against the segmented walk's 48: -1 ... -5 %: every
     // round has an epilogue of its own)
@@ -351,7 +364,7 @@ int32_t fast_tables_create(pds_stft_plan *plan, const double *window, const int3
     if (force && std::strcmp(force, "rseg") == 0) ft.walk = ft.rs_rounds > 0 ? 2 : ft.walk;
     // (matrix-pipe segments: where the segmented walk would run at two waves per SIMD or fewer -- there a
     // wave's walk is a chain of LDS round trips nobody hides; PDS_STFT_WALK=mseg: wherever built)
-    if (ft.walk == 1 && ft.ms_rounds > 0 && N >= PDS_MSEG_MIN_N && !force) ft.walk = 3;
+    if ((ft.walk == 1 || (ft.walk == 0 && ms_stands_in)) && ft.ms_rounds > 0 && N >= PDS_MSEG_MIN_N && !force) ft.walk = 3;
     if (force && std::strcmp(force, "mseg") == 0 && ft.ms_rounds > 0) ft.walk = 3;
     if (std::getenv("PDS_DEBUG_PLAN"))
       std::fprintf(stderr,

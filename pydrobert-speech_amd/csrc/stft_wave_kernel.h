@@ -185,6 +185,7 @@ struct FastParams {
   double preemph_d;  // the coefficient at full precision (float64 samples)
   int chunks_per_utt, num_utts;
   int waves;  // wavefronts per workgroup of this launch (<= MAXWAVES)
+  int area_f; // floats of a wave's private LDS area in this launch (a multiple of 4; WaveGeom::EXCH_F2 * 2 unless the walk needs less)
   unsigned waves_rcp;  // ceil(2^32 / waves): ticket / waves as a multiply-high (tickets < 2^28)
   int lds_ticket_off;  // floats from the start of the workgroup's LDS to its ticket counter
   int dyn;             // items handed out by the workgroup's ticket counter (0: static round-robin)
@@ -263,8 +264,10 @@ __device__ __forceinline__ void wave_sync() {
 // 32 columns at once takes 18.4 KB of LDS per wave -- beside the 38 KB filter table of the 64 gammatone filters at
 // 48 kHz (BASELINE.json configs[4]) six waves per CU.  Columns 0..15 and 16..31 go through the SAME 16 rows one after
 // the other instead (the second half waits, twiddled, in 32 registers: the geometry is built for two waves per SIMD
-// and has them), so a wave's area is what the power spectra and the filter walk's partial sums need, 13.5 KB, and
-// eight waves fit.  -DPDS_TWOPASS=0: the one-pass exchange of rounds 1-2 (A/B builds).
+// and has them), so a wave's area is what the power spectra and the filter walk's partial sums need: 13.5 KB and
+// eight waves per CU at first; 10.5 KB since the matrix-pipe walk keeps its sums in the accumulators across rounds
+// (mseg_tables.h), which with regenerated twiddles and the window slice read from LDS (149 VGPRs instead of 243) lets
+// that walk's launches run THREE waves per SIMD, eleven per CU.  -DPDS_TWOPASS=0: the one-pass exchange of rounds 1-2.
 #ifndef PDS_TWOPASS
 #define PDS_TWOPASS 1
 #endif
@@ -281,7 +284,8 @@ constexpr bool lean_geometry(int n1, int n2) { return PDS_LEAN_2048 && n1 == 64 
 // floats of a wave's private LDS area (exchange, then power spectra + the walks' partial sums)
 constexpr int wave_area_floats(int n1, int n2) {
   const int cols = (n1 - 1) / 2 + 1, groups = 64 / n2, one_pass = groups * cols * (n2 + 2) * 2;
-  return (PDS_TWOPASS && n1 == 64 && n2 == 16) ? 3456 : lean_geometry(n1, n2) ? groups * cols * (n2 + 4) : one_pass;
+  // (N = 1024: the power rows, 2112 floats, + 36 partial-sum slots of the matrix-pipe walk, 16 floats each)
+  return (PDS_TWOPASS && n1 == 64 && n2 == 16) ? 2688 : lean_geometry(n1, n2) ? groups * cols * (n2 + 4) : one_pass;
 }
 // floats of the window table a lean geometry keeps in LDS: [N2][stride], stride = 4 (mod 8) floats for
 // conflict-free 16-byte reads
@@ -310,7 +314,9 @@ struct WaveGeom {
   // 32-lane half write to disjoint banks
   static constexpr int PSTR = ((NB + 1 + 15) / 32) * 32 + 16;
   static_assert(GROUPS * PSTR <= EXCH_F2 * 2, "P must fit over the exchange area");
-  static constexpr int GCH = EXCH_F2 * 2 / 64 < NROWS ? EXCH_F2 * 2 / 64 : NROWS;  // rows per pass of the edge-frame gather
+  // (a launch's area may be smaller than EXCH_F2 -- FastParams::area_f -- but never smaller than the exchange)
+  static constexpr int XMIN_F = LEAN ? GROUPS * XROWS * RSF : GROUPS * XROWS * RS * 2;  // floats of the exchange itself
+  static constexpr int GCH = XMIN_F / 64 < NROWS ? XMIN_F / 64 : NROWS;  // rows per pass of the edge-frame gather
   static_assert(N % 2 == 0 && CPL >= 1 && N2 <= 64 && (RS * 8) % 16 == 0, "geometry");
   // (N = 4096 = 64 x 64 has 32 columns for 64 lanes: the upper half of the wave idles in step 3)
   static_assert(inl::is_pow2(N1) ? (FULL || N2 == 2 * COLS) : 600 % N1 == 0,
@@ -407,7 +413,7 @@ __global__ __launch_bounds__(MAXWAVES * 64, MINW) void stft_wave_kernel(const Fa
   const int rho = PAIR ? ((r & 7) * 2 + (r >> 3)) : r;
   constexpr int LOADSPAN = PAIR ? (NROWS + 1) / 2 * 32 : NROWS * N2;  // samples a frame's direct loads reach over
   [[maybe_unused]] const unsigned long long st_entry = PDS_STAMPS ? __builtin_readcyclecounter() : 0;
-  float *wbase = smem + wave * (G::EXCH_F2 * 2);
+  float *wbase = smem + wave * p.area_f;
   // (STR launches with fused CMVN sums: the wave's float64 sums, zero at the start of every piece)
   [[maybe_unused]] double *wstat = reinterpret_cast<double *>(smem + p.lds_stat_off) + wave * (2 * p.stat_cs);
   // (compiled into the stretch-scheduled kernels of the segment walks, and of the row-segment walk where the
@@ -434,7 +440,7 @@ __global__ __launch_bounds__(MAXWAVES * 64, MINW) void stft_wave_kernel(const Fa
   // weight rows.  Tables too large for LDS (dense complex banks) stay in global memory and
   // come through L1/L2.
   const int nthreads = p.waves * 64;
-  float2 *sw_lds = reinterpret_cast<float2 *>(smem + p.waves * (G::EXCH_F2 * 2));  // [N2]
+  float2 *sw_lds = reinterpret_cast<float2 *>(smem + p.waves * p.area_f);  // [N2]
   int *meta_lds = reinterpret_cast<int *>(sw_lds + N2);
   float *ellw_lds = reinterpret_cast<float *>(meta_lds + p.ell_meta_pad);
   // twiddles regenerated per item from three seeds (inl::twiddle_chain) and a window times 1/2: the float64-sample
@@ -444,7 +450,7 @@ __global__ __launch_bounds__(MAXWAVES * 64, MINW) void stft_wave_kernel(const Fa
   constexpr bool TWCHAIN = (PF && PDS_PF_TW == 1) || (PAIR && (N1 == 32 || N1 == 64)) || (PDS_DLT_CHAIN && DLT > 0 && N1 == 32 && N2 == 16) || G::LEAN ||
                            (N1 == 64 && N2 == 16 && SEG == 2);  // (the matrix-pipe walk's launches at N = 1024: the plain one prefetches, and the ragged one must give the same bits)
   constexpr bool WINLDS = PF && PDS_PF_WIN == 1;  // window slice re-read from LDS per item (in front of the item: prefetch experiment)
-  constexpr bool WINUSE = G::LEAN;                // ... read from LDS where it is applied
+  constexpr bool WINUSE = G::LEAN || (N1 == 64 && N2 == 16 && SEG == 2);  // ... read from LDS where it is applied
   constexpr int WSTR = win_table_stride(NROWS);
   [[maybe_unused]] float *win_lds = ellw_lds + (ELL_LDS ? p.ell_wfloats : 0);  // [N2][WSTR]
   if constexpr (WINLDS || WINUSE) {
@@ -489,13 +495,13 @@ __global__ __launch_bounds__(MAXWAVES * 64, MINW) void stft_wave_kernel(const Fa
   // the wave areas start out zeroed so that never-written P padding is finite
   {
     float4 *z4 = reinterpret_cast<float4 *>(smem);
-    for (int i = threadIdx.x; i < p.waves * (G::EXCH_F2 * 2 / 4); i += nthreads) z4[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    for (int i = threadIdx.x; i < p.waves * (p.area_f / 4); i += nthreads) z4[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
   }
 #else
   if constexpr (ELL_LDS)
     for (int i = threadIdx.x; i < p.ell_wfloats; i += nthreads) ellw_lds[i] = p.ell_w[i];
   // the wave areas start out zeroed so that never-written P padding is finite
-  for (int i = threadIdx.x; i < p.waves * G::EXCH_F2 * 2; i += nthreads) smem[i] = 0.0f;
+  for (int i = threadIdx.x; i < p.waves * p.area_f; i += nthreads) smem[i] = 0.0f;
 #endif
   __syncthreads();
 
@@ -1821,20 +1827,23 @@ __global__ __launch_bounds__(MAXWAVES * 64, MINW) void stft_wave_kernel(const Fa
           // ~260 cycles of matrix pipe.)
           const float4 *wbase4 = reinterpret_cast<const float4 *>(ellw_lds) + lane;
           const int last = p.seg_rounds - 1;
+          // (a round's table entry: first bin | flush << 15 | partial slot << 16 -- the block's sums stay in the
+          // instruction's accumulators across rounds and leave for their slot where the block's next unit belongs to
+          // another quad of filters, or the block ends: mseg_tables.h)
           auto meta_of = [&](int rd) { return meta_lds[(rd < last ? rd : last) * 16 + blk]; };
           auto walk = [&](auto steps_c) {
             constexpr int ST = decltype(steps_c)::value;
-            auto fetch = [&](float4 (&w)[ST], float4 (&x)[ST], const int rd, const int first) {
+            f32x4 acc0 = {0.0f, 0.0f, 0.0f, 0.0f}, acc1 = {0.0f, 0.0f, 0.0f, 0.0f};
+            auto fetch = [&](float4 (&w)[ST], float4 (&x)[ST], const int rd, const int meta) {
               const float4 *wrow = wbase4 + __mul24(rd, ST) * 64;
-              const float4 *prow = reinterpret_cast<const float4 *>(Pj + first);
+              const float4 *prow = reinterpret_cast<const float4 *>(Pj + (meta & 0x7fff));
 #pragma unroll
               for (int u = 0; u < ST; ++u) {
                 w[u] = wrow[u * 64];
                 x[u] = prow[u];
               }
             };
-            auto compute = [&](const float4 (&w)[ST], const float4 (&x)[ST], const int rd) {
-              f32x4 acc0 = {0.0f, 0.0f, 0.0f, 0.0f}, acc1 = {0.0f, 0.0f, 0.0f, 0.0f};
+            auto compute = [&](const float4 (&w)[ST], const float4 (&x)[ST], const int meta) {
 #pragma unroll
               for (int u = 0; u < ST; ++u) {
                 acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(w[u].x, x[u].x, acc0, 0, 0, 0);
@@ -1842,39 +1851,44 @@ __global__ __launch_bounds__(MAXWAVES * 64, MINW) void stft_wave_kernel(const Fa
                 acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(w[u].z, x[u].z, acc0, 0, 0, 0);
                 acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(w[u].w, x[u].w, acc1, 0, 0, 0);
               }
-              // partial slot = unit * 4 + filter of the quad, a float4 over the frames
-              float *dst = pf + (rd * 16 + blk) * 16;
-              dst[0] = acc0[0] + acc1[0];
-              dst[4] = acc0[1] + acc1[1];
-              dst[8] = acc0[2] + acc1[2];
-              dst[12] = acc0[3] + acc1[3];
+              if (meta & 0x8000) {
+                // partial slot: [filter of the quad], a float4 over the frames
+                float *dst = pf + (meta >> 16) * 16;
+                dst[0] = acc0[0] + acc1[0];
+                dst[4] = acc0[1] + acc1[1];
+                dst[8] = acc0[2] + acc1[2];
+                dst[12] = acc0[3] + acc1[3];
+                acc0 = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+                acc1 = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+              }
             };
             // (two buffers of 16 bins: 64 registers, which the 256-register geometries have; the others,
             // and longer units, run one round at a time)
             if constexpr (ST == 4 && MINW <= 2) {
               float4 wa[ST], xa[ST], wb[ST], xb[ST];
-              int fb = meta_of(1), fc = meta_of(2);
-              fetch(wa, xa, 0, meta_of(0));
+              int ma = meta_of(0), mb = meta_of(1), mc = meta_of(2);
+              fetch(wa, xa, 0, ma);
 #pragma unroll 1
               for (int rd = 0; rd <= last; rd += 2) {
-                const int fd = meta_of(rd + 3), fe = meta_of(rd + 4);
-                if (rd < last) fetch(wb, xb, rd + 1, fb);
-                compute(wa, xa, rd);
+                const int md = meta_of(rd + 3), me = meta_of(rd + 4);
+                if (rd < last) fetch(wb, xb, rd + 1, mb);
+                compute(wa, xa, ma);
                 if (rd >= last) break;
-                if (rd + 1 < last) fetch(wa, xa, rd + 2, fc);
-                compute(wb, xb, rd + 1);
-                fb = fd;
-                fc = fe;
+                if (rd + 1 < last) fetch(wa, xa, rd + 2, mc);
+                compute(wb, xb, mb);
+                ma = mc;
+                mb = md;
+                mc = me;
               }
             } else {
-              int first = meta_of(0);
+              int m = meta_of(0);
 #pragma unroll 1
               for (int rd = 0; rd <= last; ++rd) {
                 const int next = meta_of(rd + 1);
                 float4 w[ST], x[ST];
-                fetch(w, x, rd, first);
-                compute(w, x, rd);
-                first = next;
+                fetch(w, x, rd, m);
+                compute(w, x, m);
+                m = next;
               }
             }
           };
@@ -2078,6 +2092,7 @@ int32_t launch_wave(const pds_stft_plan *plan, const BatchArgs &a) {
   }
   constexpr int CU_WAVES_K = CU_WAVES_STFT;  // launch bound of the instantiations below
   int waves = CU_WAVES / 2, wgs_per_cu = 2;
+  size_t area_bytes = per_wave;  // a wave's private LDS area in this launch
   bool in_lds = false;
   // Filter walk: the plan's preferred one (fast_tables_create: fewest 16-byte LDS reads per item, or
   // PDS_STFT_WALK) when its tables fit in LDS beside the waves' areas, else the next: row segments
@@ -2097,12 +2112,16 @@ int32_t launch_wave(const pds_stft_plan *plan, const BatchArgs &a) {
   // SIMD and is not bound by the vector pipe: +2.7 %, profiles/r3j_prefetch_n1024_ab.txt; the 128-register geometry
   // and the other walks, where it measured -4 % / +-0, with -DPDS_EXPERIMENTS=1 only)
   constexpr bool PF_PRODUCT = N1 == 64 && N2 == 16;
-  constexpr bool PF_MSEG = PF_PRODUCT && G::GROUPS == 4 && inl::is_pow2(N1);  // (the plain matrix-pipe launch IS the prefetch form)
+  constexpr bool PF_MSEG = false;  // (superseded: the matrix-pipe launches of this geometry run three waves per SIMD instead, MSEG3)
+  // the matrix-pipe walk at N = 1024: launch bounds of three waves per SIMD (149 - 161 VGPRs), up to twelve waves per CU
+  constexpr bool MSEG3 = N1 == 64 && N2 == 16;
+  constexpr int MS_WAVES = MSEG3 ? 12 : 4 * MINW, MS_MINW = MSEG3 ? 3 : MINW;  // (the plain matrix-pipe launch IS the prefetch form)
   const bool pf_ok = (PDS_EXPERIMENTS || PF_PRODUCT) && PFG && !pre && !a.in_f64 && !a.stretch && a.dl_K == 0 &&
                      ft.d_win_half && ft.d_tw_seed && !(pf_env && pf_env[0] == '0');
   constexpr int PF_WSTR = ((NROWS + 3) & ~3) % 8 == 4 ? ((NROWS + 3) & ~3) : ((NROWS + 3) & ~3) + 4;
   const size_t pf_extra = (PDS_PF_WIN == 1) ? (size_t)N2 * PF_WSTR * 4 : 0;  // window table in LDS
   const size_t lean_extra = G::LEAN ? (size_t)N2 * win_table_stride(NROWS) * 4 : 0;  // ... of the lean geometries
+  const size_t mseg3_extra = (size_t)N2 * win_table_stride(NROWS) * 4;               // ... of the matrix-pipe walk at N = 1024
   constexpr bool MSG = G::GROUPS == 4 && inl::is_pow2(N1);  // matrix-pipe segment walk instantiated
   constexpr bool SEGOK = G::GROUPS == 4 || (inl::is_pow2(N1) && N2 >= 32);  // segmented walk instantiated
   for (int cand = (G::GROUPS == 4) ? (dl ? 2 : ft.walk) : (SEGOK && ft.walk == 1 ? 1 : 0); cand >= 0 && !in_lds; --cand) {
@@ -2111,18 +2130,29 @@ int32_t launch_wave(const pds_stft_plan *plan, const BatchArgs &a) {
     if ((cand == 2 && !dl && ft.rs_rounds == 0) || (cand == 1 && (ft.seg_rounds == 0 || pre || a.in_f64))) continue;
     const int meta_ints = cand == 3 ? ft.ms_meta_ints : cand == 2 ? (dl ? ft.rsn_rounds : ft.rs_rounds) * 64 : cand == 1 ? ft.seg_meta_ints : ft.ell_slots * N2;
     const int meta_pad = (std::max(meta_ints, USLOTS * N2) + 3) / 4 * 4;
-    const size_t fixed = (size_t)N2 * 8 + (size_t)meta_pad * 4 + (cand == 2 && pf_ok ? pf_extra : 0) + lean_extra;
+    const size_t fixed = (size_t)N2 * 8 + (size_t)meta_pad * 4 + (cand == 2 && pf_ok ? pf_extra : 0) + lean_extra +
+                         (cand == 3 && MSEG3 ? mseg3_extra : 0);
     const size_t table_bytes = (size_t)(cand == 3 ? ft.ms_wfloats : cand == 2 ? (dl ? ft.rsn_wfloats : ft.rs_wfloats) : cand == 1 ? ft.seg_wfloats : ft.ell_wfloats) * 4;
     // (segment sums live behind P in the wave's area)
     if (cand == 1 && (size_t)G::GROUPS * G::PSTR * 4 + (size_t)ft.seg_rounds * 64 * 4 * G::GROUPS > per_wave) continue;
-    if (cand == 3 && (size_t)G::GROUPS * G::PSTR * 4 + (size_t)ft.ms_rounds * 64 * 16 > per_wave) continue;
-    for (const auto &shape : shapes)
-      if (shape[0] * (per_wave + stat_pw) + fixed + table_bytes + 48 <= lds_cu / shape[1]) {  // (+ the ticket counter)
+    if (cand == 3 && (size_t)G::GROUPS * G::PSTR * 4 + (size_t)ft.ms_slots * 64 > per_wave) continue;
+    // (the matrix-pipe walk at N = 1024 takes the area it needs -- the exchange, or the power rows + its partial-sum
+    // slots -- instead of the geometry's: that is what lets eleven waves sit beside the 38 KB gammatone table)
+    const size_t area_c = (cand == 3 && MSEG3)
+                              ? std::max((size_t)G::XMIN_F * 4, (size_t)G::GROUPS * G::PSTR * 4 + (size_t)ft.ms_slots * 64)
+                              : per_wave;
+    const int ms_shapes[5][2] = {{12, 1}, {11, 1}, {10, 1}, {9, 1}, {8, 1}};
+    const int (*try_shapes)[2] = (cand == 3 && MSEG3) ? ms_shapes : shapes;
+    for (int si = 0; si < ((cand == 3 && MSEG3) ? 5 : 4); ++si) {
+      const int *shape = try_shapes[si];
+      if (shape[0] * (area_c + stat_pw) + fixed + table_bytes + 48 <= lds_cu / shape[1]) {  // (+ the ticket counter)
         waves = shape[0];
         wgs_per_cu = shape[1];
         in_lds = true;
+        area_bytes = area_c;
         break;
       }
+    }
     p.ell_meta_pad = meta_pad;
     p.ell_meta_ints = meta_ints;
     if (in_lds && cand == 3) {
@@ -2149,7 +2179,8 @@ int32_t launch_wave(const pds_stft_plan *plan, const BatchArgs &a) {
 #ifdef PDS_FORCE_WAVES  // (experiment: throughput against resident waves per CU, two workgroups per CU)
   if (in_lds && PDS_FORCE_WAVES <= CU_WAVES / 2) waves = PDS_FORCE_WAVES, wgs_per_cu = 2;
 #endif
-  const size_t fixed = (size_t)N2 * 8 + (size_t)p.ell_meta_pad * 4 + (walk == 2 && in_lds && pf_ok ? pf_extra : 0) + lean_extra;
+  const size_t fixed = (size_t)N2 * 8 + (size_t)p.ell_meta_pad * 4 + (walk == 2 && in_lds && pf_ok ? pf_extra : 0) + lean_extra +
+                       (walk == 3 && in_lds && MSEG3 ? mseg3_extra : 0);
   const size_t table_bytes = (size_t)p.ell_wfloats * 4;
   // the fused pre-emphasis variant exists for LDS-resident tables only; the rare other case
   // (dense complex bank at N >= 1024 plus pre-emphasis) takes the direct-DFT kernel
@@ -2163,7 +2194,8 @@ int32_t launch_wave(const pds_stft_plan *plan, const BatchArgs &a) {
 #else
   p.stamps = nullptr;
 #endif
-  size_t smem = waves * per_wave + fixed + (in_lds ? table_bytes : 0);
+  p.area_f = (int)(area_bytes / 4);
+  size_t smem = waves * area_bytes + fixed + (in_lds ? table_bytes : 0);
   smem = (smem + 15) & ~(size_t)15;
   p.lds_ticket_off = (int)(smem / 4);  // the workgroup's ticket counter
   smem += 16;
@@ -2182,7 +2214,7 @@ int32_t launch_wave(const pds_stft_plan *plan, const BatchArgs &a) {
   auto kern = pre      ? (rsg ? stft_wave_kernel<N1, N2, NROWS, CU_WAVES_K, MINW, true, true, false, 0, W4>
                               : stft_wave_kernel<N1, N2, NROWS, CU_WAVES_K, MINW, true, true>)
               : rsg    ? stft_wave_kernel<N1, N2, NROWS, CU_WAVES_K, MINW, true, false, false, 0, W4>
-              : mseg   ? stft_wave_kernel<N1, N2, NROWS, CU_WAVES_K, MINW, true, false, MSG ? 2 : 0, 0, false, float, float, 0, false, PF_MSEG>
+              : mseg   ? stft_wave_kernel<N1, N2, NROWS, MS_WAVES, MS_MINW, true, false, MSG ? 2 : 0>
               : seg    ? stft_wave_kernel<N1, N2, NROWS, CU_WAVES_K, MINW, true, false, SEGOK ? 1 : 0>
               : in_lds ? stft_wave_kernel<N1, N2, NROWS, CU_WAVES_K, MINW, true, false>
                        : stft_wave_kernel<N1, N2, NROWS, CU_WAVES_K, MINW, false, false>;
@@ -2202,8 +2234,8 @@ int32_t launch_wave(const pds_stft_plan *plan, const BatchArgs &a) {
     }
   }
   bool pf_used = false;
-  if (PF_MSEG && mseg && !pre) {
-    p.win_half = ft.d_win_half;  // (regenerated twiddles: see the kernel)
+  if (MSEG3 && mseg) {
+    p.win_half = ft.d_win_half;  // (regenerated twiddles, window slice from LDS: see the kernel)
     p.tw_seed = (const float2 *)ft.d_tw_seed;
   }
 #if PDS_EXPERIMENTS
@@ -2226,7 +2258,7 @@ int32_t launch_wave(const pds_stft_plan *plan, const BatchArgs &a) {
   if (a.stretch && !pre && !a.in_f64 && a.dl_K == 0 && !mf && a.d_chunk_prefix) {
     str_used = true;
     kern = rsg      ? stft_wave_kernel<N1, N2, NROWS, CU_WAVES_K, MINW, true, false, 0, 0, W4, float, float, 0, true>
-           : mseg   ? stft_wave_kernel<N1, N2, NROWS, CU_WAVES_K, MINW, true, false, MSG ? 2 : 0, 0, false, float, float, 0, true>
+           : mseg   ? stft_wave_kernel<N1, N2, NROWS, MS_WAVES, MS_MINW, true, false, MSG ? 2 : 0, 0, false, float, float, 0, true>
            : seg    ? stft_wave_kernel<N1, N2, NROWS, CU_WAVES_K, MINW, true, false, SEGOK ? 1 : 0, 0, false, float, float, 0, true>
            : in_lds ? stft_wave_kernel<N1, N2, NROWS, CU_WAVES_K, MINW, true, false, 0, 0, false, float, float, 0, true>
                     : stft_wave_kernel<N1, N2, NROWS, CU_WAVES_K, MINW, false, false, 0, 0, false, float, float, 0, true>;
