@@ -163,10 +163,9 @@ int32_t pds_stft_batch_ragged_f32(const pds_stft_plan *plan, const float *d_sign
  * deltas are formed in float32 where pds_deltas_rows_f32 (and the reference) accumulate in float64
  * and round: they agree within a few float32 ulps of the statics, i.e. inside the feature tolerance.
  * Served for plans with transform sizes 512 and 1024 whose banks run the row-segment filter walk in
- * at most two rounds (mel banks of up to ~100 filters): pds_stft_plan_has_fused_deltas().  (The statics agree
- * with pds_stft_batch_f32's within the feature tolerance, not bit for bit: at N = 512 the one-launch kernel
- * regenerates its inter-stage twiddles per item -- 1.3e-7 from the table's -- to make room for a fourth wave per
- * SIMD, and a plan that prefers another filter walk for the plain launch sums in another order.) */
+ * at most two rounds (mel banks of up to ~100 filters): pds_stft_plan_has_fused_deltas().  (The statics are
+ * bit-identical to pds_stft_batch_f32's when that launch takes the row-segment walk too; a plan that prefers
+ * another walk for the plain launch sums the same products in another order: a few float32 ulps.) */
 int32_t pds_stft_plan_has_fused_deltas(const pds_stft_plan *plan);
 /* ... with everything the reference's drivers put in front of compute_full (command_line.py:345-350): `d_signal`
  * float32 (signal_is_f64 = 0) or float64 samples (1: plans with pds_stft_plan_has_f64in(); rounded to float32 as the

@@ -533,10 +533,9 @@ class ShortTimeFourierTransformFrameComputer(LinearFilterBankFrameComputer):
         frame r followed by its order-1 .. order-K deltas: :func:`launch` into rows of that stride
         followed by ``deltas.apply_rows``.  ``fused=True`` asks for the one-launch form
         (``pds_stft_deltas_batch_f32``: transform sizes 512 and 1024, mel-like banks, ``Deltas(1 or 2)``
-        with the default context window and padding): the statics agree with :func:`launch`'s within the
-        feature tolerance (a few float32 ulps: regenerated twiddles), the deltas are formed in float32 from
-        coefficients held in registers (within a few float32 ulps of the statics of the float64-accumulated
-        ones) and nothing is read back from memory.  It is what runs
+        with the default context window and padding): the statics are the same bit for bit, the deltas
+        are formed in float32 from coefficients held in registers (within a few float32 ulps of the
+        statics of the float64-accumulated ones) and nothing is read back from memory.  It is what runs
         when ``fused`` is left at ``None`` and the plan has it (1.34 x the rate of the two launches on
         BASELINE.json configs[2]); ``fused=False`` keeps the two launches, whose deltas are numpy's bit
         for bit.

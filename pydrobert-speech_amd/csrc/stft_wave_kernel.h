@@ -144,12 +144,8 @@ extern unsigned long long *g_stamp_buf;  // (stft_fast.hip: pds_debug_set_stamp_
 #ifndef PDS_PF_TW
 #define PDS_PF_TW 1
 #endif
-// The one-launch statics + deltas kernel of the 32 x 16 geometry regenerates its twiddles and reads its window slice
-// from LDS like the float64-sample kernels: 129 VGPRs instead of 156, FOUR waves per SIMD for float32 samples
-// (configs[2]: 0.483 -> 0.473 ms; the same kernel at three waves per SIMD: 0.515 -- the fourth wave is worth more than
-// the 50 instructions and 7 LDS reads it costs).  -DPDS_DLT_CHAIN=0 -DPDS_DLT_MINW=3: the form of round 2.
-#ifndef PDS_DLT_CHAIN
-#define PDS_DLT_CHAIN 1
+#ifndef PDS_DLT_CHAIN  // (experiment: regenerated twiddles in the one-launch statics + deltas kernel, float32 samples too)
+#define PDS_DLT_CHAIN 0
 #endif
 #ifndef PDS_PF_WIN
 #define PDS_PF_WIN 0
@@ -454,9 +450,7 @@ __global__ __launch_bounds__(MAXWAVES * 64, MINW) void stft_wave_kernel(const Fa
   constexpr bool TWCHAIN = (PF && PDS_PF_TW == 1) || (PAIR && (N1 == 32 || N1 == 64)) || (PDS_DLT_CHAIN && DLT > 0 && N1 == 32 && N2 == 16) || G::LEAN ||
                            (N1 == 64 && N2 == 16 && SEG == 2);  // (the matrix-pipe walk's launches at N = 1024: the plain one prefetches, and the ragged one must give the same bits)
   constexpr bool WINLDS = PF && PDS_PF_WIN == 1;  // window slice re-read from LDS per item (in front of the item: prefetch experiment)
-  constexpr bool WINUSE = G::LEAN || (N1 == 64 && N2 == 16 && SEG == 2) ||
-                          (PDS_DLT_CHAIN && DLT > 0 && N1 == 32 && N2 == 16 && std::is_same<TIN, float>::value);  // ... read from LDS where it is applied
-  // (the float64-sample one-launch kernels stay at three waves per SIMD, where the LDS window costs 6 % and buys nothing)
+  constexpr bool WINUSE = G::LEAN || (N1 == 64 && N2 == 16 && SEG == 2);  // ... read from LDS where it is applied
   constexpr int WSTR = win_table_stride(NROWS);
   [[maybe_unused]] float *win_lds = ellw_lds + (ELL_LDS ? p.ell_wfloats : 0);  // [N2][WSTR]
   if constexpr (WINLDS || WINUSE) {
@@ -2030,13 +2024,12 @@ int32_t launch_wave(const pds_stft_plan *plan, const BatchArgs &a) {
   using G = WaveGeom<N1, N2, NROWS>;
   // resident waves per CU that the register budget allows; the fused statics + deltas instantiations
   // hold their window in registers and run three waves per SIMD where the others run four
-#ifndef PDS_DLT_MINW  // (waves per SIMD of the one-launch statics + deltas kernel, float32 samples; see PDS_DLT_CHAIN)
-#define PDS_DLT_MINW 4
+#ifndef PDS_DLT_MINW  // (experiment: 4 = the one-launch statics + deltas kernel at four waves per SIMD, twiddles regenerated)
+#define PDS_DLT_MINW 3
 #endif
   constexpr int DMINW = MINW > PDS_DLT_MINW ? PDS_DLT_MINW : MINW;
-  constexpr int DMINW64 = MINW > 3 ? 3 : MINW;  // (float64 samples: the pair loads keep 52 registers in flight)
   constexpr int CU_WAVES_STFT = 4 * MINW;
-  const int CU_WAVES = a.dl_K > 0 ? 4 * (a.in_f64 ? DMINW64 : DMINW) : CU_WAVES_STFT;
+  const int CU_WAVES = a.dl_K > 0 ? 4 * DMINW : CU_WAVES_STFT;
   const FastTables &ft = plan->fast;
   FastParams p;
   p.sig = a.d_signal;
@@ -2129,7 +2122,6 @@ int32_t launch_wave(const pds_stft_plan *plan, const BatchArgs &a) {
   const size_t pf_extra = (PDS_PF_WIN == 1) ? (size_t)N2 * PF_WSTR * 4 : 0;  // window table in LDS
   const size_t lean_extra = G::LEAN ? (size_t)N2 * win_table_stride(NROWS) * 4 : 0;  // ... of the lean geometries
   const size_t mseg3_extra = (size_t)N2 * win_table_stride(NROWS) * 4;               // ... of the matrix-pipe walk at N = 1024
-  const size_t dlt_extra = (PDS_DLT_CHAIN && a.dl_K > 0 && !a.in_f64 && N1 == 32 && N2 == 16) ? (size_t)N2 * win_table_stride(NROWS) * 4 : 0;
   constexpr bool MSG = G::GROUPS == 4 && inl::is_pow2(N1);  // matrix-pipe segment walk instantiated
   constexpr bool SEGOK = G::GROUPS == 4 || (inl::is_pow2(N1) && N2 >= 32);  // segmented walk instantiated
   for (int cand = (G::GROUPS == 4) ? (dl ? 2 : ft.walk) : (SEGOK && ft.walk == 1 ? 1 : 0); cand >= 0 && !in_lds; --cand) {
@@ -2139,7 +2131,7 @@ int32_t launch_wave(const pds_stft_plan *plan, const BatchArgs &a) {
     const int meta_ints = cand == 3 ? ft.ms_meta_ints : cand == 2 ? (dl ? ft.rsn_rounds : ft.rs_rounds) * 64 : cand == 1 ? ft.seg_meta_ints : ft.ell_slots * N2;
     const int meta_pad = (std::max(meta_ints, USLOTS * N2) + 3) / 4 * 4;
     const size_t fixed = (size_t)N2 * 8 + (size_t)meta_pad * 4 + (cand == 2 && pf_ok ? pf_extra : 0) + lean_extra +
-                         (cand == 3 && MSEG3 ? mseg3_extra : 0) + dlt_extra;
+                         (cand == 3 && MSEG3 ? mseg3_extra : 0);
     const size_t table_bytes = (size_t)(cand == 3 ? ft.ms_wfloats : cand == 2 ? (dl ? ft.rsn_wfloats : ft.rs_wfloats) : cand == 1 ? ft.seg_wfloats : ft.ell_wfloats) * 4;
     // (segment sums live behind P in the wave's area)
     if (cand == 1 && (size_t)G::GROUPS * G::PSTR * 4 + (size_t)ft.seg_rounds * 64 * 4 * G::GROUPS > per_wave) continue;
@@ -2188,7 +2180,7 @@ int32_t launch_wave(const pds_stft_plan *plan, const BatchArgs &a) {
   if (in_lds && PDS_FORCE_WAVES <= CU_WAVES / 2) waves = PDS_FORCE_WAVES, wgs_per_cu = 2;
 #endif
   const size_t fixed = (size_t)N2 * 8 + (size_t)p.ell_meta_pad * 4 + (walk == 2 && in_lds && pf_ok ? pf_extra : 0) + lean_extra +
-                       (walk == 3 && in_lds && MSEG3 ? mseg3_extra : 0) + dlt_extra;
+                       (walk == 3 && in_lds && MSEG3 ? mseg3_extra : 0);
   const size_t table_bytes = (size_t)p.ell_wfloats * 4;
   // the fused pre-emphasis variant exists for LDS-resident tables only; the rare other case
   // (dense complex bank at N >= 1024 plus pre-emphasis) takes the direct-DFT kernel
@@ -2325,8 +2317,8 @@ int32_t launch_wave(const pds_stft_plan *plan, const BatchArgs &a) {
       }
       mf = false;
       using D = double;
-      kern = a.in_f64 ? (pre ? stft_wave_kernel<N1, N2, NROWS, 4 * DMINW64, DMINW64, true, true, false, 0, true, D, float, 2>
-                             : stft_wave_kernel<N1, N2, NROWS, 4 * DMINW64, DMINW64, true, false, false, 0, true, D, float, 2>)
+      kern = a.in_f64 ? (pre ? stft_wave_kernel<N1, N2, NROWS, 4 * DMINW, DMINW, true, true, false, 0, true, D, float, 2>
+                             : stft_wave_kernel<N1, N2, NROWS, 4 * DMINW, DMINW, true, false, false, 0, true, D, float, 2>)
                       : (pre ? stft_wave_kernel<N1, N2, NROWS, 4 * DMINW, DMINW, true, true, false, 0, true, float, float, 2>
                              : stft_wave_kernel<N1, N2, NROWS, 4 * DMINW, DMINW, true, false, false, 0, true, float, float, 2>);
       if (a.in_f64 || PDS_DLT_CHAIN) {

@@ -27,28 +27,18 @@ sigs = {
     "gaussian x 1e-3": torch.randn(total, device=dev).mul_(1e-3),
 }
 layout = comp.prepare_layout(offsets, lengths, device=dev)
-deltas = ps.post.Deltas(2) if post == "deltas2" else None  # (workloads with deltas: the one-launch statics + deltas kernel)
-out = torch.empty((layout.total_rows, comp.num_coeffs * (3 if deltas is not None else 1)), dtype=torch.float32, device=dev)
-
-
-def launch(x):
-    if deltas is not None:
-        comp.launch_with_deltas(x, layout, deltas, out=out, fused=True)
-    else:
-        comp.launch(x, layout, out=out)
-
-
+out = torch.empty((layout.total_rows, comp.num_coeffs), dtype=torch.float32, device=dev)
 for _ in range(400):
-    launch(sigs["gaussian x 3000"])
+    comp.launch(sigs["gaussian x 3000"], layout, out=out)
 torch.cuda.synchronize()
 for rep in range(3):
     for name, x in sigs.items():
         for _ in range(100):
-            launch(x)
+            comp.launch(x, layout, out=out)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(200):
-            launch(x)
+            comp.launch(x, layout, out=out)
         e1.record()
         torch.cuda.synchronize()
         print(f"{wl} {name:18s} {e0.elapsed_time(e1) / 200:.4f} ms per launch")
