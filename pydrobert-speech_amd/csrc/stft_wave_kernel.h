@@ -144,6 +144,12 @@ extern unsigned long long *g_stamp_buf;  // (stft_fast.hip: pds_debug_set_stamp_
 #ifndef PDS_PF_TW
 #define PDS_PF_TW 1
 #endif
+// Every kernel of the 64 x 16 geometry (N = 1024) regenerates its twiddles and reads its window slice from LDS: 146 - 168
+// VGPRs instead of 220 - 243, three waves per SIMD (stft_geoms.def) -- this geometry is bound by its waves' latencies,
+// not by the vector pipe.  -DPDS_LEAN_1024=0 with the geometry's MINW back at 2: the form of round 2.
+#ifndef PDS_LEAN_1024
+#define PDS_LEAN_1024 1
+#endif
 #ifndef PDS_DLT_CHAIN  // (experiment: regenerated twiddles in the one-launch statics + deltas kernel, float32 samples too)
 #define PDS_DLT_CHAIN 0
 #endif
@@ -448,9 +454,9 @@ __global__ __launch_bounds__(MAXWAVES * 64, MINW) void stft_wave_kernel(const Fa
   // rows: with thirty registers of twiddles beside them the kernel spilled 10 ... 34 registers), and the prefetch
   // experiment
   constexpr bool TWCHAIN = (PF && PDS_PF_TW == 1) || (PAIR && (N1 == 32 || N1 == 64)) || (PDS_DLT_CHAIN && DLT > 0 && N1 == 32 && N2 == 16) || G::LEAN ||
-                           (N1 == 64 && N2 == 16 && SEG == 2);  // (the matrix-pipe walk's launches at N = 1024: the plain one prefetches, and the ragged one must give the same bits)
+                           (N1 == 64 && N2 == 16 && (SEG == 2 || PDS_LEAN_1024));  // (N = 1024: the matrix-pipe walk's launches, which run three waves per SIMD; PDS_LEAN_1024: every kernel of the geometry)
   constexpr bool WINLDS = PF && PDS_PF_WIN == 1;  // window slice re-read from LDS per item (in front of the item: prefetch experiment)
-  constexpr bool WINUSE = G::LEAN || (N1 == 64 && N2 == 16 && SEG == 2);  // ... read from LDS where it is applied
+  constexpr bool WINUSE = G::LEAN || (N1 == 64 && N2 == 16 && (SEG == 2 || PDS_LEAN_1024));  // ... read from LDS where it is applied
   constexpr int WSTR = win_table_stride(NROWS);
   [[maybe_unused]] float *win_lds = ellw_lds + (ELL_LDS ? p.ell_wfloats : 0);  // [N2][WSTR]
   if constexpr (WINLDS || WINUSE) {
@@ -2027,9 +2033,12 @@ int32_t launch_wave(const pds_stft_plan *plan, const BatchArgs &a) {
 #ifndef PDS_DLT_MINW  // (experiment: 4 = the one-launch statics + deltas kernel at four waves per SIMD, twiddles regenerated)
 #define PDS_DLT_MINW 3
 #endif
-  constexpr int DMINW = MINW > PDS_DLT_MINW ? PDS_DLT_MINW : MINW;
+  // (N = 1024: the one-launch statics + deltas kernel keeps two waves per SIMD -- at three it spills 25 - 33 registers)
+  constexpr int DMINW = (N1 == 64 && N2 == 16) ? 2 : MINW > PDS_DLT_MINW ? PDS_DLT_MINW : MINW;
   constexpr int CU_WAVES_STFT = 4 * MINW;
-  const int CU_WAVES = a.dl_K > 0 ? 4 * DMINW : CU_WAVES_STFT;
+  // (N = 1024: the float64-sample kernels keep two waves per SIMD -- their pair loads hold 120 registers in flight)
+  constexpr int F64_MINW = (N1 == 64 && N2 == 16) ? 2 : MINW, F64_WAVES = 4 * F64_MINW;
+  const int CU_WAVES = a.dl_K > 0 ? 4 * DMINW : a.in_f64 ? F64_WAVES : CU_WAVES_STFT;
   const FastTables &ft = plan->fast;
   FastParams p;
   p.sig = a.d_signal;
@@ -2042,8 +2051,9 @@ int32_t launch_wave(const pds_stft_plan *plan, const BatchArgs &a) {
   p.win_lane = ft.d_window;
   p.tw_lane = (const float2 *)ft.d_twiddle;
   p.tw_special = (const float2 *)ft.d_tw_special;
-  p.win_half = G::LEAN ? ft.d_win_half : nullptr;  // (lean geometries: every instantiation regenerates its twiddles)
-  p.tw_seed = G::LEAN ? (const float2 *)ft.d_tw_seed : nullptr;
+  constexpr bool LEAN_ALL = G::LEAN || (PDS_LEAN_1024 && N1 == 64 && N2 == 16);  // every instantiation regenerates its twiddles
+  p.win_half = LEAN_ALL ? ft.d_win_half : nullptr;
+  p.tw_seed = LEAN_ALL ? (const float2 *)ft.d_tw_seed : nullptr;
   p.ell_w = ft.d_ell_w;
   p.ell_meta = ft.d_ell_meta;
   p.ell_len = ft.d_ell_len;
@@ -2115,13 +2125,14 @@ int32_t launch_wave(const pds_stft_plan *plan, const BatchArgs &a) {
   constexpr bool PF_MSEG = false;  // (superseded: the matrix-pipe launches of this geometry run three waves per SIMD instead, MSEG3)
   // the matrix-pipe walk at N = 1024: launch bounds of three waves per SIMD (149 - 161 VGPRs), up to twelve waves per CU
   constexpr bool MSEG3 = N1 == 64 && N2 == 16;
-  constexpr int MS_WAVES = MSEG3 ? 12 : 4 * MINW, MS_MINW = MSEG3 ? 3 : MINW;  // (the plain matrix-pipe launch IS the prefetch form)
+  constexpr int MS_WAVES = MSEG3 ? 12 : 4 * MINW, MS_MINW = MSEG3 ? 3 : MINW;
+  static_assert(!MSEG3 || !PDS_LEAN_1024 || MINW == 3, "the 64 x 16 geometry is instantiated for three waves per SIMD (stft_geoms.def)");  // (the plain matrix-pipe launch IS the prefetch form)
   const bool pf_ok = (PDS_EXPERIMENTS || PF_PRODUCT) && PFG && !pre && !a.in_f64 && !a.stretch && a.dl_K == 0 &&
                      ft.d_win_half && ft.d_tw_seed && !(pf_env && pf_env[0] == '0');
   constexpr int PF_WSTR = ((NROWS + 3) & ~3) % 8 == 4 ? ((NROWS + 3) & ~3) : ((NROWS + 3) & ~3) + 4;
   const size_t pf_extra = (PDS_PF_WIN == 1) ? (size_t)N2 * PF_WSTR * 4 : 0;  // window table in LDS
-  const size_t lean_extra = G::LEAN ? (size_t)N2 * win_table_stride(NROWS) * 4 : 0;  // ... of the lean geometries
-  const size_t mseg3_extra = (size_t)N2 * win_table_stride(NROWS) * 4;               // ... of the matrix-pipe walk at N = 1024
+  const size_t lean_extra = LEAN_ALL ? (size_t)N2 * win_table_stride(NROWS) * 4 : 0;  // ... of the lean geometries
+  const size_t mseg3_extra = LEAN_ALL ? 0 : (size_t)N2 * win_table_stride(NROWS) * 4;  // ... of the matrix-pipe walk at N = 1024 alone
   constexpr bool MSG = G::GROUPS == 4 && inl::is_pow2(N1);  // matrix-pipe segment walk instantiated
   constexpr bool SEGOK = G::GROUPS == 4 || (inl::is_pow2(N1) && N2 >= 32);  // segmented walk instantiated
   for (int cand = (G::GROUPS == 4) ? (dl ? 2 : ft.walk) : (SEGOK && ft.walk == 1 ? 1 : 0); cand >= 0 && !in_lds; --cand) {
@@ -2255,13 +2266,13 @@ int32_t launch_wave(const pds_stft_plan *plan, const BatchArgs &a) {
   // (power-of-two geometries; the others keep the round-robin order, which skips the chunks short utterances lack)
   bool str_used = false;
   if constexpr (inl::is_pow2(N1))
-  if (a.stretch && !pre && !a.in_f64 && a.dl_K == 0 && !mf && a.d_chunk_prefix) {
+  // (tables in LDS: a bank whose table stays in global memory keeps the round-robin order)
+  if (a.stretch && !pre && !a.in_f64 && a.dl_K == 0 && !mf && a.d_chunk_prefix && in_lds) {
     str_used = true;
     kern = rsg      ? stft_wave_kernel<N1, N2, NROWS, CU_WAVES_K, MINW, true, false, 0, 0, W4, float, float, 0, true>
            : mseg   ? stft_wave_kernel<N1, N2, NROWS, MS_WAVES, MS_MINW, true, false, MSG ? 2 : 0, 0, false, float, float, 0, true>
            : seg    ? stft_wave_kernel<N1, N2, NROWS, CU_WAVES_K, MINW, true, false, SEGOK ? 1 : 0, 0, false, float, float, 0, true>
-           : in_lds ? stft_wave_kernel<N1, N2, NROWS, CU_WAVES_K, MINW, true, false, 0, 0, false, float, float, 0, true>
-                    : stft_wave_kernel<N1, N2, NROWS, CU_WAVES_K, MINW, false, false, 0, 0, false, float, float, 0, true>;
+                    : stft_wave_kernel<N1, N2, NROWS, CU_WAVES_K, MINW, true, false, 0, 0, false, float, float, 0, true>;
     p.chunk_prefix = a.d_chunk_prefix;
   }
   if (a.d_stat_part) {
@@ -2288,14 +2299,14 @@ int32_t launch_wave(const pds_stft_plan *plan, const BatchArgs &a) {
       p.win_half = ft.d_win_half;  // (16-lane geometries: twiddles regenerated from seeds, see the kernel)
       p.tw_seed = (const float2 *)ft.d_tw_seed;
       if (a.out_f64)
-        kern = rsg ? stft_wave_kernel<N1, N2, NROWS, CU_WAVES_K, MINW, true, false, false, 0, W4, double, double>
-                   : stft_wave_kernel<N1, N2, NROWS, CU_WAVES_K, MINW, true, false, false, 0, false, double, double>;
+        kern = rsg ? stft_wave_kernel<N1, N2, NROWS, F64_WAVES, F64_MINW, true, false, false, 0, W4, double, double>
+                   : stft_wave_kernel<N1, N2, NROWS, F64_WAVES, F64_MINW, true, false, false, 0, false, double, double>;
       else if (pre)
-        kern = rsg ? stft_wave_kernel<N1, N2, NROWS, CU_WAVES_K, MINW, true, true, false, 0, W4, double, float>
-                   : stft_wave_kernel<N1, N2, NROWS, CU_WAVES_K, MINW, true, true, false, 0, false, double, float>;
+        kern = rsg ? stft_wave_kernel<N1, N2, NROWS, F64_WAVES, F64_MINW, true, true, false, 0, W4, double, float>
+                   : stft_wave_kernel<N1, N2, NROWS, F64_WAVES, F64_MINW, true, true, false, 0, false, double, float>;
       else
-        kern = rsg ? stft_wave_kernel<N1, N2, NROWS, CU_WAVES_K, MINW, true, false, false, 0, W4, double, float>
-                   : stft_wave_kernel<N1, N2, NROWS, CU_WAVES_K, MINW, true, false, false, 0, false, double, float>;
+        kern = rsg ? stft_wave_kernel<N1, N2, NROWS, F64_WAVES, F64_MINW, true, false, false, 0, W4, double, float>
+                   : stft_wave_kernel<N1, N2, NROWS, F64_WAVES, F64_MINW, true, false, false, 0, false, double, float>;
       f64_which = 12 + (a.out_f64 ? 4 : pre ? 2 : 0) + (rsg ? 1 : 0);
     } else {
       set_error("stft_batch_f64in: no fused float64-input kernel for this transform size");
@@ -2351,7 +2362,7 @@ int32_t launch_wave(const pds_stft_plan *plan, const BatchArgs &a) {
   const int which = dl_which >= 0    ? dl_which
                     : f64_which >= 0 ? f64_which
                     : pf_used        ? (rsg ? 27 : mseg ? 30 : 31)
-                    : str_used       ? 22 + (rsg ? 0 : mseg ? 1 : seg ? 2 : in_lds ? 3 : 4)
+                    : str_used       ? 22 + (rsg ? 0 : mseg ? 1 : seg ? 2 : 3)
                     : mseg           ? 20
                                      : (pre ? (rsg ? 5 : 2) : rsg ? 4 : seg ? 3 : (in_lds ? 1 : 0)) + (mf ? 6 : 0);
   const bool cached = plan->device >= 0 && plan->device < kDevices;

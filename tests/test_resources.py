@@ -47,7 +47,7 @@ DEFAULT_PATH = [
     _key(32, 16, 25, 12, 3, dlt=2, pre="T", tin="d"),
     _key(32, 16, 25, 16, 4, seg=1, rsg="F"),                  # configs[3]: Gabor-64, segmented walk
     _key(64, 16, 60, 12, 3, seg=2, rsg="F"),                  # configs[4]: gammatone-64 at 48 kHz, matrix-pipe segments, 3 waves per SIMD
-    _key(64, 16, 60, 8, 2),                                   # 20 ms frames at 48 kHz, mel bank
+    _key(64, 16, 60, 12, 3),                                  # 20 ms frames at 48 kHz, mel bank
     _key(64, 16, 60, 8, 2, tin="d"),
     _key(64, 16, 60, 8, 2, pre="T", tin="d"),
     _key(64, 32, 38, 12, 3, rsg="F"),                         # 25 ms frames at 48 kHz (N = 2048, lean form)
