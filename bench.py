@@ -92,6 +92,12 @@ WORKLOADS = {
          "frame_length_ms": 50, "frame_shift_ms": 12.5, "use_power": True},
         480000, 256, None,
     ),
+    # ... 80 ms frames (3840 samples: every one of the 64 rows of the N = 4096 geometry in use)
+    "fbank80_48k_80_20_b256x10s": (
+        {"name": "stft", "bank": {"name": "fbank", "num_filts": 80, "sampling_rate": 48000},
+         "frame_length_ms": 80, "frame_shift_ms": 20, "use_power": True},
+        480000, 256, None,
+    ),
     # short-integration features, 40 complex Gabor filters (supports up
     # to 380 taps) + energy; compute bound (direct time-domain filtering), so a smaller batch
     "si_gabor40_b64x10s": (
