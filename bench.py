@@ -244,6 +244,76 @@ def parity_spot_check(comp, signal, offsets, lengths, layout, out, picks=3, num_
             "against": "oracle/stft_oracle.compute_full (float64) on the timed buffer's own input"}
 
 
+def _hwmon_of_device(dev_index=0):
+    """hwmon directory (socket power / shader clock sensors) of the HIP device, matched by its PCI address;
+    None when the sysfs files are not there"""
+    import glob
+
+    import torch
+
+    try:
+        pr = torch.cuda.get_device_properties(dev_index)
+        want = "%04x:%02x:%02x.0" % (pr.pci_domain_id, pr.pci_bus_id, pr.pci_device_id)
+    except Exception:
+        want = None
+    found = []
+    for card in glob.glob("/sys/class/drm/card*/device"):
+        for hw in glob.glob(os.path.join(card, "hwmon", "hwmon*")):
+            if os.path.exists(os.path.join(hw, "power1_input")):
+                found.append((os.path.basename(os.path.realpath(card)), hw))
+    for addr, hw in found:
+        if want is not None and addr.lower() == want:
+            return hw, True
+    return (found[0][1], False) if len(found) == 1 else (None, False)
+
+
+def power_probe(step, sync, seconds=1.2):
+    """The socket power and shader clock the chip holds under back-to-back steps (tools/power_sample.py: the headline
+    kernel runs AT the 1400 W cap, at ~1.94 GHz instead of 2.4): a thread samples the device's hwmon files while the
+    steps run; the second half of the samples is averaged (the power reading is a moving average)."""
+    import threading
+
+    hw, matched = _hwmon_of_device()
+    if hw is None:
+        return None
+
+    def rd(name):
+        try:
+            with open(os.path.join(hw, name)) as fh:
+                return float(fh.read().strip())
+        except (OSError, ValueError):
+            return None
+
+    samples, stop = [], threading.Event()
+
+    def sampler():
+        while not stop.is_set():
+            samples.append((rd("power1_input"), rd("freq1_input")))
+            time.sleep(0.02)
+
+    th = threading.Thread(target=sampler, daemon=True)
+    th.start()
+    t0 = time.perf_counter()
+    n = 0
+    while time.perf_counter() - t0 < seconds:
+        for _ in range(50):
+            step()
+        sync()
+        n += 50
+    elapsed = time.perf_counter() - t0
+    stop.set()
+    th.join()
+    tail = [s for s in samples[len(samples) // 2:] if s[0] is not None]
+    if not tail:
+        return None
+    cap = rd("power1_cap")
+    freqs = [s[1] for s in tail if s[1] is not None]
+    return {"socket_w": float(np.mean([s[0] for s in tail])) * 1e-6, "cap_w": cap * 1e-6 if cap else None,
+            "sclk_mhz": float(np.mean(freqs)) * 1e-6 if freqs else None, "sclk_max_mhz": 2400.0,
+            "ms_per_step_during_probe": 1e3 * elapsed / n, "samples": len(tail), "sensor_matched_by_pci_address": matched,
+            "source": "hwmon power1_input / freq1_input of the device, sampled every 20 ms over %.1f s of back-to-back steps" % seconds}
+
+
 def _stdout_to_stderr():
     """Send file descriptor 1 to stderr until the JSON line: libraries (RCCL prints a version
     banner on stdout when its communicator is created) must not add lines to the one the driver
@@ -266,6 +336,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--no-power-probe", action="store_true",
+                    help="skip the 1.2 s of extra steps under which socket power and shader clock are sampled")
     ap.add_argument("--preroll-ms", type=float, default=60.0,
                     help="untimed launches before the warm-up, for at least this many milliseconds and until "
                          "the step time has settled: the GPU leaves its idle clock state only after ~40 ms "
@@ -472,6 +544,12 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     finite = bool(torch.isfinite(out).all().item())
+    power = None
+    if rank == 0 and world == 1 and not args.no_power_probe:
+        try:
+            power = power_probe(step, lambda: torch.cuda.synchronize(dev))
+        except Exception as exc:  # an optional leg
+            power = {"error": repr(exc)[:200]}
     # The CPU-baseline leg (one spawned worker per host core for ~15 s) comes after the timed region: run in
     # front of it, the GPU steps that followed were paced by a host still busy winding the workers down --
     # 0.308 ms per step against 0.269 ms for the same kernel (rocprofv3 kernel trace, profiles/r2d_*), i.e.
@@ -584,6 +662,8 @@ def main():
                 "algorithmic_bytes_per_frame": bytes_per_frame,
                 "frames_per_s_per_gpu_kernel_only": frames / k_avg_s,
                 "secondary": secondary,
+                # the limit this kernel actually runs into on MI355X: the socket's power cap
+                "power": power,
             },
             "cold_ms_per_step": cold_ms,
             "outputs_finite": finite,
