@@ -198,6 +198,8 @@ def parity_spot_check(comp, signal, offsets, lengths, layout, out, picks=3, num_
     utts = sorted({0, B // 2, B - 1})[:picks]
     for b in utts:
         x = signal[int(offsets[b]) : int(offsets[b] + lengths[b])].cpu().numpy()
+        if x.dtype.kind == "i":  # (int16 PCM: the reference's readers cast it before anything else, util.py:211-234)
+            x = x.astype(np.float64)
         if preemph:
             x = orc.preemphasize(x, preemph)
         want = orc.compute_full(x, p)
@@ -272,6 +274,8 @@ def power_probe(step, sync, seconds=1.2):
     kernel runs AT the 1400 W cap, at ~1.94 GHz instead of 2.4): a thread samples the device's hwmon files while the
     steps run; the second half of the samples is averaged (the power reading is a moving average)."""
     import threading
+
+    import numpy as np
 
     hw, matched = _hwmon_of_device()
     if hw is None:
@@ -348,9 +352,10 @@ def main():
     ap.add_argument("--ragged", action="store_true",
                     help="utterance lengths uniform in [1 s, 15 s] at the workload's rate (seed 99; "
                          "SURVEY.md section 8(d)) instead of the workload's fixed length")
-    ap.add_argument("--dtype", default="f32", choices=["f32", "f64in"],
+    ap.add_argument("--dtype", default="f32", choices=["f32", "f64in", "i16in"],
                     help="f64in: float64 samples in HBM, rounded to float32 by the fused kernel as it loads the "
-                         "frames (pds_stft_batch_f64in), float32 features -- the reference drivers' dtype flow")
+                         "frames (pds_stft_batch_f64in), float32 features -- the reference drivers' dtype flow; "
+                         "i16in: int16 PCM in HBM, converted at the frame load (pds_stft_batch_i16in)")
     ap.add_argument("--fused-deltas", action="store_true",
                     help="deltas2 workloads: statics and deltas by one launch (the default where the plan has one)")
     ap.add_argument("--two-launch-deltas", action="store_true",
@@ -438,6 +443,10 @@ def main():
             raise SystemExit("--dtype f64in: STFT workloads only")
         signal = signal.double()
         ps.config.FLOAT64_ARITHMETIC = "float32"
+    if args.dtype == "i16in":
+        if is_si or post is not None:
+            raise SystemExit("--dtype i16in: STFT workloads without a post-processor only")
+        signal = signal.clamp_(-32768, 32767).to(torch.int16)
     if is_si:
         layout = None
         frames = int(sum(comp.num_frames(int(v)) for v in lengths))
@@ -592,7 +601,7 @@ def main():
 
     if rank == 0:
         # every sample read once, every output coefficient written once
-        bytes_per_frame = (8 if args.dtype == "f64in" else 4) * comp.frame_shift + 4 * out_cols
+        bytes_per_frame = {"f64in": 8, "i16in": 2}.get(args.dtype, 4) * comp.frame_shift + 4 * out_cols
         if cmvn is not None:
             bytes_per_frame += 4 * C + 8 * C  # second read of the features + float64 result
         k_avg_s = 1e-3 * float(np.mean(kernel_ms))
@@ -638,11 +647,12 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f64in->f32" if args.dtype == "f64in" else "f32",  # (samples in HBM -> arithmetic and features)
+            "dtype": {"f64in": "f64in->f32", "i16in": "i16in->f32"}.get(args.dtype, "f32"),  # (samples in HBM -> arithmetic and features)
             "data": "synthetic",
             "config": {
                 "workload": args.workload + ("+ragged_1to15s" if args.ragged else "")
                             + ("+float64_samples" if args.dtype == "f64in" else "")
+                            + ("+int16_samples" if args.dtype == "i16in" else "")
                             + (f"+preemph{args.preemph:g}" if args.preemph else ""), "utterances_per_gpu": B,
                 "samples_per_utterance": int(lengths.mean()),
                 "frames_per_gpu_per_step": frames, "num_coeffs": comp.num_coeffs, "post": post,

@@ -139,6 +139,18 @@ int32_t pds_stft_batch_f64in(const pds_stft_plan *plan, const double *d_signal,
                              const int64_t *d_nframes, const int64_t *d_row_off, int32_t B,
                              int64_t max_frames, int32_t pad_left, double preemph, void *d_out,
                              int32_t out_is_f64, int64_t out_stride, void *stream);
+/* int16 samples (PCM as a WAV file holds it; what scipy.io.wavfile / wave hand the reference's readers before
+ * their .astype(dtype), util.py:207-235) -> float32 features: every sample is converted to float32 as its frame
+ * is loaded (exact), then the arithmetic of pds_stft_batch_f32 -- a fused pre-emphasis included -- so the result
+ * equals pds_stft_batch_f32 on the converted signal.  Half the bytes of float32 samples, a quarter of the
+ * reference drivers' float64 ones, over PCIe and out of HBM; no conversion pass on the host or the device.
+ * Served for the plans pds_stft_plan_has_f64in() serves (pds_stft_plan_has_i16in()). */
+int32_t pds_stft_plan_has_i16in(const pds_stft_plan *plan);
+int32_t pds_stft_batch_i16in(const pds_stft_plan *plan, const int16_t *d_signal,
+                             const int64_t *d_offsets, const int64_t *d_lengths,
+                             const int64_t *d_nframes, const int64_t *d_row_off, int32_t B,
+                             int64_t max_frames, int32_t pad_left, double preemph, float *d_out,
+                             int64_t out_stride, void *stream);
 /* pds_stft_batch_f32 (reference compute.py:574-607, compute_full per utterance) for RAGGED batches: the same kernels, but every wave walks one contiguous stretch of the
  * chunks that exist (the utterances' chunk counts are summed into `d_workspace`, B + 1 int64 on the device, by
  * a small kernel in front) instead of the waves being dealt (utterance, chunk < chunks of the longest) pairs of

@@ -203,6 +203,25 @@ int32_t pds_stft_batch_f64in(const pds_stft_plan *plan, const double *d_signal, 
   return pds::launch_stft_fast_f32(plan, a);
 }
 
+int32_t pds_stft_plan_has_i16in(const pds_stft_plan *plan) { return plan && pds::fast_has_f64in(plan) ? 1 : 0; }
+
+int32_t pds_stft_batch_i16in(const pds_stft_plan *plan, const int16_t *d_signal, const int64_t *d_offsets,
+                             const int64_t *d_lengths, const int64_t *d_nframes, const int64_t *d_row_off,
+                             int32_t B, int64_t max_frames, int32_t pad_left, double preemph, float *d_out,
+                             int64_t out_stride, void *stream) {
+  int32_t rc = check_batch(plan, d_signal, d_offsets, d_lengths, d_nframes, d_row_off, B, max_frames, pad_left,
+                           d_out, out_stride);
+  if (rc == 1) return PDS_OK;
+  if (rc != PDS_OK) return rc;
+  if (!pds::fast_has_f64in(plan)) return invalid("stft_batch_i16in: the plan has no fused int16-input kernel");
+  rc = pds::check_plan_device(plan->device, "stft_batch");
+  if (rc != PDS_OK) return rc;
+  pds::BatchArgs a{d_signal,   d_offsets, d_lengths,  d_nframes, d_row_off, B, max_frames,
+                   pad_left < 0 ? plan->d.pad_left : pad_left, preemph, d_out, out_stride, (hipStream_t)stream};
+  a.in_i16 = true;
+  return pds::launch_stft_fast_f32(plan, a);
+}
+
 int32_t pds_stft_plan_has_fused_deltas(const pds_stft_plan *plan) {
   return plan && pds::fast_has_fused_deltas(plan) ? 1 : 0;
 }

@@ -127,6 +127,8 @@ struct BatchArgs {
   // fused kernel only: float64 samples rounded at the frame load / float64 features widened at the
   // store (float32 arithmetic either way); pds_stft_batch_f64in
   bool in_f64 = false, out_f64 = false;
+  // fused kernel only: int16 samples converted at the frame load (pds_stft_batch_i16in)
+  bool in_i16 = false;
   // fused statics + deltas (pds_stft_deltas_batch_f32): order (0 = none) and the taps, order 1 then 2
   int dl_K = 0;
   double dl_taps[16] = {0};

@@ -396,6 +396,7 @@ __global__ __launch_bounds__(MAXWAVES * 64, MINW) void stft_wave_kernel(const Fa
   static_assert(DLT == 0 || (DLT == 2 && N2 == 16 && RSG && std::is_same<TOUT, float>::value && MF == 0),
                 "fused deltas: row-segment walk, float32 features");
   static_assert(MF == 0 || std::is_same<TIN, float>::value, "matrix-pipe front end: float32 samples");
+  static_assert(std::is_same<TIN, float>::value || std::is_same<TIN, double>::value || std::is_same<TIN, int16_t>::value, "samples: float32, float64 or int16");
   using G = WaveGeom<N1, N2, NROWS>;
   constexpr int N = G::N, COLS = G::COLS, NREG = G::NREG, RS = G::RS, NB = G::NB, PSTR = G::PSTR;
   constexpr int MSLOTS = 2 * MF + 1;  // per-lane sample slots of a frame (MF)
@@ -415,7 +416,8 @@ __global__ __launch_bounds__(MAXWAVES * 64, MINW) void stft_wave_kernel(const Fa
   // (a masked row_ror:8 each way) and lane s owns residue 2s, lane s + 8 residue 2s + 1 of EVERY row.
   // `rho` is the residue (n2) whose samples, window and twiddles the lane holds until the exchange;
   // it is `r` everywhere else.
-  constexpr bool PAIR = !std::is_same<TIN, float>::value && N2 == 16 && MF == 0;
+  constexpr bool F64S = std::is_same<TIN, double>::value;  // float64 samples (int16 samples convert like float32 ones)
+  constexpr bool PAIR = F64S && N2 == 16 && MF == 0;
   const int rho = PAIR ? ((r & 7) * 2 + (r >> 3)) : r;
   constexpr int LOADSPAN = PAIR ? (NROWS + 1) / 2 * 32 : NROWS * N2;  // samples a frame's direct loads reach over
   [[maybe_unused]] const unsigned long long st_entry = PDS_STAMPS ? __builtin_readcyclecounter() : 0;
@@ -1117,7 +1119,7 @@ __global__ __launch_bounds__(MAXWAVES * 64, MINW) void stft_wave_kernel(const Fa
             if (2 * j + 1 < NROWS)
               a[2 * j + 1] = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(fv), __float_as_int(fu), 0x128, 0xf, 0x3, false));
           }
-        } else if constexpr (!std::is_same<TIN, float>::value) {
+        } else if constexpr (F64S) {
           // float64 samples: 8-byte loads, pre-emphasis in float64 (bit-identical to the reference's
           // own pass, pre.py:140-149), one rounding to float32
 #pragma unroll
@@ -1130,7 +1132,7 @@ __global__ __launch_bounds__(MAXWAVES * 64, MINW) void stft_wave_kernel(const Fa
 #pragma unroll
         for (int n1 = 0; n1 < NROWS; ++n1) a[n1] = (PDS_ABLATE & 1) ? (float)(lane + n1) : (float)xp[n1 * N2];
         }
-        if constexpr (PRE && std::is_same<TIN, float>::value) {
+        if constexpr (PRE && !F64S) {  // (int16 samples: converted above, pre-emphasised like float32 ones)
           // predecessor of lane r's sample: lane r - 1 of the same row, or (r = 0) the last lane
           // of the previous row.  With 16 lanes per frame a lane group is one DPP row and
           // row_ror:1 delivers both; other group sizes load the predecessor.
@@ -1167,7 +1169,7 @@ __global__ __launch_bounds__(MAXWAVES * 64, MINW) void stft_wave_kernel(const Fa
               } else {
                 i = (int)reflect_index((int64_t)i, (int64_t)n);
               }
-              if constexpr (std::is_same<TIN, float>::value) {
+              if constexpr (!F64S) {
                 v = (float)x[i];
                 if (PRE && i > 0) v = preemph_sample(v, (float)x[i - 1], p.preemph);
               } else {
@@ -2127,7 +2129,7 @@ int32_t launch_wave(const pds_stft_plan *plan, const BatchArgs &a) {
   constexpr bool MSEG3 = N1 == 64 && N2 == 16;
   constexpr int MS_WAVES = MSEG3 ? 12 : 4 * MINW, MS_MINW = MSEG3 ? 3 : MINW;
   static_assert(!MSEG3 || !PDS_LEAN_1024 || MINW == 3, "the 64 x 16 geometry is instantiated for three waves per SIMD (stft_geoms.def)");  // (the plain matrix-pipe launch IS the prefetch form)
-  const bool pf_ok = (PDS_EXPERIMENTS || PF_PRODUCT) && PFG && !pre && !a.in_f64 && !a.stretch && a.dl_K == 0 &&
+  const bool pf_ok = (PDS_EXPERIMENTS || PF_PRODUCT) && PFG && !pre && !a.in_f64 && !a.in_i16 && !a.stretch && a.dl_K == 0 &&
                      ft.d_win_half && ft.d_tw_seed && !(pf_env && pf_env[0] == '0');
   constexpr int PF_WSTR = ((NROWS + 3) & ~3) % 8 == 4 ? ((NROWS + 3) & ~3) : ((NROWS + 3) & ~3) + 4;
   const size_t pf_extra = (PDS_PF_WIN == 1) ? (size_t)N2 * PF_WSTR * 4 : 0;  // window table in LDS
@@ -2136,9 +2138,9 @@ int32_t launch_wave(const pds_stft_plan *plan, const BatchArgs &a) {
   constexpr bool MSG = G::GROUPS == 4 && inl::is_pow2(N1);  // matrix-pipe segment walk instantiated
   constexpr bool SEGOK = G::GROUPS == 4 || (inl::is_pow2(N1) && N2 >= 32);  // segmented walk instantiated
   for (int cand = (G::GROUPS == 4) ? (dl ? 2 : ft.walk) : (SEGOK && ft.walk == 1 ? 1 : 0); cand >= 0 && !in_lds; --cand) {
-    if (cand == 3 && (!MSG || ft.ms_rounds == 0 || pre || a.in_f64)) continue;
+    if (cand == 3 && (!MSG || ft.ms_rounds == 0 || pre || a.in_f64 || a.in_i16)) continue;
     // (no segmented variant of the fused pre-emphasis kernel)
-    if ((cand == 2 && !dl && ft.rs_rounds == 0) || (cand == 1 && (ft.seg_rounds == 0 || pre || a.in_f64))) continue;
+    if ((cand == 2 && !dl && ft.rs_rounds == 0) || (cand == 1 && (ft.seg_rounds == 0 || pre || a.in_f64 || a.in_i16))) continue;
     const int meta_ints = cand == 3 ? ft.ms_meta_ints : cand == 2 ? (dl ? ft.rsn_rounds : ft.rs_rounds) * 64 : cand == 1 ? ft.seg_meta_ints : ft.ell_slots * N2;
     const int meta_pad = (std::max(meta_ints, USLOTS * N2) + 3) / 4 * 4;
     const size_t fixed = (size_t)N2 * 8 + (size_t)meta_pad * 4 + (cand == 2 && pf_ok ? pf_extra : 0) + lean_extra +
@@ -2195,6 +2197,10 @@ int32_t launch_wave(const pds_stft_plan *plan, const BatchArgs &a) {
   const size_t table_bytes = (size_t)p.ell_wfloats * 4;
   // the fused pre-emphasis variant exists for LDS-resident tables only; the rare other case
   // (dense complex bank at N >= 1024 plus pre-emphasis) takes the direct-DFT kernel
+  if (a.in_i16 && !in_lds) {
+    set_error("stft_batch_i16in: not served for this plan (filter table outside LDS)");
+    return PDS_ERR_INVALID;
+  }
   if (pre && !in_lds) return launch_stft_generic_f32(plan, a);
   p.preemph = (float)a.preemph;
   p.preemph_d = a.preemph;
@@ -2267,7 +2273,7 @@ int32_t launch_wave(const pds_stft_plan *plan, const BatchArgs &a) {
   bool str_used = false;
   if constexpr (inl::is_pow2(N1))
   // (tables in LDS: a bank whose table stays in global memory keeps the round-robin order)
-  if (a.stretch && !pre && !a.in_f64 && a.dl_K == 0 && !mf && a.d_chunk_prefix && in_lds) {
+  if (a.stretch && !pre && !a.in_f64 && !a.in_i16 && a.dl_K == 0 && !mf && a.d_chunk_prefix && in_lds) {
     str_used = true;
     kern = rsg      ? stft_wave_kernel<N1, N2, NROWS, CU_WAVES_K, MINW, true, false, 0, 0, W4, float, float, 0, true>
            : mseg   ? stft_wave_kernel<N1, N2, NROWS, MS_WAVES, MS_MINW, true, false, MSG ? 2 : 0, 0, false, float, float, 0, true>
@@ -2310,6 +2316,28 @@ int32_t launch_wave(const pds_stft_plan *plan, const BatchArgs &a) {
       f64_which = 12 + (a.out_f64 ? 4 : pre ? 2 : 0) + (rsg ? 1 : 0);
     } else {
       set_error("stft_batch_f64in: no fused float64-input kernel for this transform size");
+      return PDS_ERR_INVALID;
+    }
+  }
+  // int16 samples (pds_stft_batch_i16in: PCM as it sits in a WAV file, half the bytes of float32 over PCIe and from
+  // HBM): converted as the frame is loaded, then exactly the float32 kernel; the geometries of the float64-sample
+  // path, ELL or row-segment walk, LDS-resident tables
+  int i16_which = -1;
+  if (a.in_i16) {
+    constexpr bool I16IN = fast_f64in_kind(N1 * N2);
+    if constexpr (I16IN) {
+      if (a.in_f64 || a.out_f64 || a.dl_K > 0 || a.d_stat_part) {
+        set_error("stft_batch_i16in: float32 features, no fused deltas / CMVN sums");
+        return PDS_ERR_INVALID;
+      }
+      mf = false;
+      kern = pre ? (rsg ? stft_wave_kernel<N1, N2, NROWS, CU_WAVES_K, MINW, true, true, false, 0, W4, int16_t, float>
+                        : stft_wave_kernel<N1, N2, NROWS, CU_WAVES_K, MINW, true, true, false, 0, false, int16_t, float>)
+                 : (rsg ? stft_wave_kernel<N1, N2, NROWS, CU_WAVES_K, MINW, true, false, false, 0, W4, int16_t, float>
+                        : stft_wave_kernel<N1, N2, NROWS, CU_WAVES_K, MINW, true, false, false, 0, false, int16_t, float>);
+      i16_which = 32 + (pre ? 2 : 0) + (rsg ? 1 : 0);
+    } else {
+      set_error("stft_batch_i16in: no fused int16-input kernel for this transform size");
       return PDS_ERR_INVALID;
     }
   }
@@ -2358,9 +2386,10 @@ int32_t launch_wave(const pds_stft_plan *plan, const BatchArgs &a) {
   // the dynamic-LDS limit is an attribute of the kernel on one device: raised once per
   // (instantiation, device, variant) and remembered (relaxed atomics: a lost race repeats the call)
   constexpr int kDevices = 64;
-  static std::atomic<size_t> attr_smem[kDevices][32];
+  static std::atomic<size_t> attr_smem[kDevices][36];
   const int which = dl_which >= 0    ? dl_which
                     : f64_which >= 0 ? f64_which
+                    : i16_which >= 0 ? i16_which
                     : pf_used        ? (rsg ? 27 : mseg ? 30 : 31)
                     : str_used       ? 22 + (rsg ? 0 : mseg ? 1 : seg ? 2 : 3)
                     : mseg           ? 20

@@ -450,6 +450,59 @@ def test_fused_float64_input_with_preemphasis(computers, golden_tables, master_s
         assert_features_close(got[rows[b] : rows[b + 1]], orc.compute_full(y, p), rtol=2e-4, atol=2e-5)
 
 
+@pytest.mark.parametrize("preemph", [0.0, 0.97], ids=["plain", "preemph"])
+@pytest.mark.parametrize("name", ["c1_kaldi_fbank", "c2_tri_mel40", "c3_fbank80_energy", "c4_gabor64", "c5_gammatone64_48k"])
+def test_fused_int16_input_kernel(name, preemph, computers, golden_tables, monkeypatch):
+    """pds_stft_batch_i16in: int16 PCM straight into the fused kernel (converted at the frame load; the reference's
+    readers hold such samples before their .astype, util.py:207-235): against the oracle on the converted signal,
+    and equal to the float32 launch on it bit for bit where both take the same filter walk -- with no conversion
+    pass (the launch must not call .to)"""
+    import torch
+
+    comp = computers[name]
+    if not comp._native_plan().has_i16in:
+        pytest.skip("no fused int16-input kernel for this transform size")
+    p = oracle_params(golden_tables, name)
+    rng = np.random.default_rng(5)
+    lens = [0, 1, 150, comp.frame_length // 2 + 1, 2000, 16001, 4801]
+    sigs = [rng.integers(-32768, 32768, size=n).astype(np.int16) for n in lens]
+    sigs[4][:] = np.where(rng.random(lens[4]) < 0.5, -32768, 32767)  # (full scale: the largest magnitudes the format holds)
+    offs = np.concatenate([[0], np.cumsum(lens)[:-1]])
+    packed = torch.from_numpy(np.concatenate(sigs)).cuda()
+    as_float = packed.to(torch.float32)
+    layout = comp.prepare_layout(offs, lens, device=packed.device)
+    rows = layout.row_offsets
+    monkeypatch.setattr(torch.Tensor, "to", lambda *a, **k: pytest.fail("the launch converted a tensor"))
+    feats = comp.launch(packed, layout, preemphasis=preemph)
+    monkeypatch.undo()
+    assert feats.dtype == torch.float32 and feats.shape == (int(rows[-1]), comp.num_coeffs)
+    same = comp.launch(as_float, layout, preemphasis=preemph)
+    # (dense banks take another filter walk for float32 samples: tolerance instead of equality there)
+    if not torch.equal(feats, same):
+        assert_features_close(feats.cpu().numpy(), same.cpu().numpy(), rtol=2e-5, atol=2e-6)
+    got = feats.cpu().numpy()
+    for b, x in enumerate(sigs):
+        y = x.astype(np.float64)
+        if preemph:
+            y[1:] -= preemph * x[:-1].astype(np.float64)
+        tol = dict(rtol=2e-4, atol=2e-5) if preemph else F32
+        assert_features_close(got[rows[b] : rows[b + 1]], orc.compute_full(y, p), what=(name, b), **tol)
+
+
+def test_int16_input_without_a_fused_kernel_converts_first(golden_tables):
+    # a transform size the int16 instantiations do not cover (N = L = 400 without padding): same features
+    import torch
+
+    cfg = {"name": "stft", "bank": {"name": "fbank", "num_filts": 40}, "frame_length_ms": 25, "frame_shift_ms": 10,
+           "pad_to_nearest_power_of_two": False}
+    comp = build(cfg)
+    rng = np.random.default_rng(6)
+    x = torch.from_numpy(rng.integers(-3000, 3000, size=16000).astype(np.int16)).cuda()
+    got, _ = comp.compute_packed(x, [0], [16000])
+    want, _ = comp.compute_packed(x.to(torch.float32), [0], [16000])
+    assert got.dtype == torch.float32 and torch.equal(got, want)
+
+
 @pytest.mark.parametrize("name", ["c1_kaldi_fbank", "c2_tri_mel40", "v_tri_analytic_nolog", "v_gabor_nopad_mag"])
 def test_streaming_random_chunkings_match_reference_call_by_call(name, computers, master_signal):
     # tests/golden/make_golden_stream.py: eight lengths (one sample .. 4000) x random cut points;

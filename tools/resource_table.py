@@ -82,7 +82,7 @@ def short(name):
         except OSError:
             return name[:100]
     args = m.group(1)
-    toks = re.findall(r"Li(\d+)E|Lb([01])E|([fd])", args)
+    toks = re.findall(r"Li(\d+)E|Lb([01])E|([fds])", args)
     vals = [a or ("T" if b == "1" else "F" if b else c) for a, b, c in toks]
     names = ["N1", "N2", "ROWS", "MAXW", "MINW", "ELL_LDS", "PRE", "SEG", "MF", "RSG", "TIN", "TOUT", "DLT", "STR", "PF"]
     return "stft_wave<" + " ".join(f"{n}={v}" for n, v in zip(names, vals)) + ">"
