@@ -232,6 +232,61 @@ int32_t pds_stft_batch_f32_generic(const pds_stft_plan *plan, const float *d_sig
                                    float *d_out, int64_t out_stride, void *stream);
 
 /* ---------------------------------------------------------------------------------
+ * Host feed: utterances in HOST memory through a plan and back (csrc/feed.hip).
+ *
+ * The reference's callers hold their audio on the host -- compute_full(signal) takes a numpy array
+ * (compute.py:574), signals-to-torch-feat-dir reads files (command_line.py:337-607).  For them the rate of
+ * the path is what it makes of PCIe: the kernel needs 0.27 ms for a batch the link needs ~12 ms to deliver.
+ * A feed is a ring of `slots` staging slots on the current device -- pinned host buffers for samples and
+ * features, their device twins, one stream each -- so that batch k + 1 uploads while batch k computes and
+ * batch k - 1 downloads.  Samples travel as they are stored (PDS_SAMPLES_I16: 2 bytes per sample, converted as
+ * a frame is loaded; PDS_SAMPLES_F64: the reference drivers' float64, rounded as a frame is loaded).
+ *
+ *   pds_feed_acquire  the ring's next slot (blocks until its previous batch was released) and the pinned host
+ *                     buffer the caller -- its reader threads -- fills with the batch's utterances back to back
+ *   pds_feed_pack     optional: fills that buffer from one host pointer per utterance with `threads` copying
+ *                     threads (a single memcpy stream does not keep up with the link)
+ *   pds_feed_submit   lengths of the utterances packed there; queues upload + kernel (+ download of the
+ *                     features when `download` != 0) on the slot's stream and returns at once
+ *   pds_feed_device_view / pds_feed_download
+ *                     after a submit with download = 0: the device features, the slot's stream -- queue
+ *                     post-processors (pds_deltas_rows_f32, pds_cmvn_rows_f32out, ...) on it -- then the download of
+ *                     whatever device buffer holds the final rows (at most slot_rows x feature_cols float32)
+ *   pds_feed_collect  blocks until the slot's download has arrived: float32 rows in pinned host memory and the
+ *                     utterances' n_utts + 1 row offsets (both valid until pds_feed_release)
+ *   pds_feed_unpack   optional: the collected features copied out of the pinned buffer by `threads` copying threads
+ *   pds_feed_release  gives the slot back to the ring
+ * Slots are acquired, and must be collected and released, in ring order.  One thread may feed (acquire / pack /
+ * submit) while another drains (collect / release).
+ * --------------------------------------------------------------------------------- */
+#define PDS_SAMPLES_F32 0
+#define PDS_SAMPLES_F64 1
+#define PDS_SAMPLES_I16 2
+typedef struct pds_feed pds_feed;
+/* slot_samples / slot_utts: capacity of one slot; a slot holds slot_rows = slot_samples / frame_shift + slot_utts
+ * rows.  feature_cols: float32 columns per row the slot's feature buffers have room for (0 or less than the
+ * plan's num_coeffs: num_coeffs) -- more when a post-processor queued on the slot's stream widens the rows
+ * (Deltas: (K + 1) num_coeffs) and its result is what pds_feed_download sends back */
+int32_t pds_feed_create(const pds_stft_plan *plan, int32_t sample_format, int64_t slot_samples, int32_t slot_utts,
+                        int32_t slots, int32_t feature_cols, pds_feed **feed_out);
+void pds_feed_destroy(pds_feed *feed);
+int64_t pds_feed_slot_rows(const pds_feed *feed);
+int32_t pds_feed_acquire(pds_feed *feed, int32_t *slot_out, void **h_samples_out);
+int32_t pds_feed_pack(pds_feed *feed, int32_t slot, const void *const *signals, const int64_t *lengths, int32_t n_utts,
+                      int32_t threads);
+int32_t pds_feed_submit(pds_feed *feed, int32_t slot, const int64_t *lengths, int32_t n_utts, double preemph,
+                        int32_t download);
+int32_t pds_feed_device_view(pds_feed *feed, int32_t slot, void **d_features, int64_t *rows, const int64_t **row_offsets,
+                             void **stream);
+int32_t pds_feed_download(pds_feed *feed, int32_t slot, const void *d_src, int64_t bytes);
+int32_t pds_feed_collect(pds_feed *feed, int32_t slot, const float **h_features, const int64_t **row_offsets,
+                         int64_t *rows);
+/* optional, between collect and release: the first `bytes` of the slot's features copied to ordinary host memory
+ * by `threads` copying threads */
+int32_t pds_feed_unpack(pds_feed *feed, int32_t slot, void *dst, int64_t bytes, int32_t threads);
+int32_t pds_feed_release(pds_feed *feed, int32_t slot);
+
+/* ---------------------------------------------------------------------------------
  * Pre-processors as separate passes (reference pre.py:67-149); `preemph` above fuses the
  * first one into the frame load instead.
  * pds_preemphasize: per utterance of a packed buffer (offsets/lengths as in pds_stft_batch),

@@ -17,12 +17,13 @@ without the built library or without a HIP device raises.
 """
 from . import alias, compute, config, filters, post, pre, scales, util  # noqa: F401
 from . import si  # noqa: F401  (registers the "si" computer with the FrameComputer aliases)
+from . import feed  # noqa: F401
 
 # the reference keeps both computers in one module (compute.py:613, 996)
 compute.ShortIntegrationFrameComputer = si.ShortIntegrationFrameComputer
 compute.SIFrameComputer = si.SIFrameComputer
 from ._native import LIB_PATH, NativeError  # noqa: F401
 
-__all__ = ["alias", "compute", "config", "filters", "post", "pre", "scales", "si", "util"]
+__all__ = ["alias", "compute", "config", "feed", "filters", "post", "pre", "scales", "si", "util"]
 # ``pydrobert_speech_amd.torch`` (nn.Module faces) and ``.command_line`` import torch: on demand
 __version__ = "0.1.0"

@@ -155,6 +155,19 @@ SIGNATURES = {
     "pds_cmvn_apply_f64": (c_int32, [c_void_p, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
     "pds_cmvn_rows_f32": (c_int32, _CMVN_ROWS_ARGS),
     "pds_cmvn_rows_f32out": (c_int32, _CMVN_ROWS_ARGS),
+    # host feed (pinned staging ring: upload / kernel / download of consecutive batches overlap)
+    "pds_feed_create": (c_int32, [c_void_p, c_int32, c_int64, c_int32, c_int32, c_int32, POINTER(c_void_p)]),
+    "pds_feed_destroy": (None, [c_void_p]),
+    "pds_feed_slot_rows": (c_int64, [c_void_p]),
+    "pds_feed_acquire": (c_int32, [c_void_p, POINTER(c_int32), POINTER(c_void_p)]),
+    "pds_feed_pack": (c_int32, [c_void_p, c_int32, c_void_p, c_void_p, c_int32, c_int32]),
+    "pds_feed_submit": (c_int32, [c_void_p, c_int32, c_void_p, c_int32, c_double, c_int32]),
+    "pds_feed_device_view": (c_int32, [c_void_p, c_int32, POINTER(c_void_p), POINTER(c_int64), POINTER(c_void_p),
+                                       POINTER(c_void_p)]),
+    "pds_feed_download": (c_int32, [c_void_p, c_int32, c_void_p, c_int64]),
+    "pds_feed_collect": (c_int32, [c_void_p, c_int32, POINTER(c_void_p), POINTER(c_void_p), POINTER(c_int64)]),
+    "pds_feed_unpack": (c_int32, [c_void_p, c_int32, c_void_p, c_int64, c_int32]),
+    "pds_feed_release": (c_int32, [c_void_p, c_int32]),
     # multi-GPU gather over RCCL
     "pds_comm_unique_id": (c_int32, [c_void_p]),
     "pds_comm_init_rank": (c_int32, [c_void_p, c_int32, c_int32, POINTER(c_void_p)]),

@@ -5,7 +5,11 @@ Same command line and on-disk result as the reference's tool -- a text map of
 (``FloatTensor (T, F)``), ``--manifest`` resume -- but the work is organised for the device:
 
 * signals are read by a pool of host threads (``--num-workers``) while the GPU works on the
-  previous batch;
+  previous batch; 16-bit PCM stays int16 until a frame is loaded on the device (a quarter of the
+  bytes of the reference's float64 arrays over PCIe; the conversion is exact);
+* a batch goes through the pinned staging ring of ``feed.HostFeed`` where the chain allows (an STFT
+  computer with a fused kernel, at most a pre-emphasis in front): upload, kernels and download are
+  queued on one stream without a host concatenate or a pageable copy;
 * a batch of utterances (``--batch-utts`` / ``--batch-samples``) is packed into one device
   buffer and goes through ONE launch per stage: dither, pre-emphasis (fused into the frame
   loader when it is the last pre-processor), the fused STFT/filter-bank kernel, then each
@@ -107,6 +111,7 @@ class FeatureDirWriter:
         self.out_dir, self.channel, self.force_as, self.seed = out_dir, channel, force_as, seed
         self.prefix, self.suffix, self.manifest = file_prefix, file_suffix, manifest
         self.dtype = np.dtype(precision)
+        self._feeds = {}  # sample dtype -> HostFeed
         os.makedirs(out_dir, exist_ok=True)
 
     # -- host side ----------------------------------------------------------------------------
@@ -114,9 +119,13 @@ class FeatureDirWriter:
     def read(self, utt_id: str, path: str) -> np.ndarray:
         """One mono signal; channel rules and messages of the reference (command_line.py:104-126)"""
         try:
-            signal = read_signal(path, dtype=self.dtype, force_as=self.force_as, key=utt_id)
+            # (native dtype: 16-bit PCM travels as int16 in float32 precision -- the cast the reference does right
+            # here, command_line.py:107-108, happens on the device as the frames are loaded, exactly)
+            signal = read_signal(path, dtype=None, force_as=self.force_as, key=utt_id)
         except Exception as exc:
             raise IOError(f"Utterance {utt_id}: {exc}") from exc
+        if not (signal.dtype == np.int16 and self.dtype == np.float32):
+            signal = signal.astype(self.dtype, copy=False)
         if self.channel == -1 and signal.ndim > 1 and signal.shape[0] > 1:
             raise ValueError(
                 f"Utterance {utt_id}: Channel is not specified but signal has shape {signal.shape}")
@@ -135,8 +144,16 @@ class FeatureDirWriter:
 
         lengths = np.asarray([len(s) for s in signals], dtype=np.int64)
         offsets = np.concatenate([[0], np.cumsum(lengths)]).astype(np.int64)
+        kinds = {s.dtype for s in signals}
+        if len(kinds) > 1:  # (a batch of PCM and float files)
+            signals = [s.astype(self.dtype, copy=False) for s in signals]
+        through_feed = self._process_through_feed(signals, lengths)
+        if through_feed is not None:
+            return through_feed
         host = np.concatenate(signals) if offsets[-1] else np.zeros(0, self.dtype)
         packed = torch.from_numpy(host).to("cuda")
+        if packed.dtype == torch.int16:
+            packed = packed.to(torch.float32)  # (uploaded as PCM, widened on the device)
         fused = 0.0
         for k, pre in enumerate(self.pre):
             if isinstance(pre, Dither):
@@ -154,6 +171,51 @@ class FeatureDirWriter:
             feats, rows = self.computer.compute_packed(packed, offsets[:-1], lengths, **kwargs)
         feats, rows = self._postprocess(feats, np.asarray(rows, dtype=np.int64))
         feats = feats.to(torch.float32).cpu()
+        return [feats[rows[b] : rows[b + 1]].clone() for b in range(len(signals))]
+
+    def _process_through_feed(self, signals, lengths):
+        """The batch through the pinned staging ring (``feed.HostFeed``) when the chain allows: an STFT computer
+        with a fused kernel, float32 precision, no pre-processor but a pre-emphasis (which rides along with the frame
+        loads); else ``None``"""
+        import torch
+
+        from .feed import HostFeed
+
+        comp = self.computer
+        if comp is None or self.dtype != np.float32 or not getattr(comp, "fuses_preemphasis", False) or not len(signals):
+            return None
+        if len(self.pre) > 1 or (self.pre and not isinstance(self.pre[0], Preemphasize)) or not int(lengths.sum()):
+            return None
+        dtype = signals[0].dtype
+        plan = comp._native_plan()
+        if not plan.kernel_kind or (dtype == np.int16 and not plan.has_i16in) or dtype not in (np.float32, np.int16):
+            return None
+        C = comp.num_coeffs
+        key = np.dtype(dtype)
+        feed = self._feeds.get(key)
+        need_samples, need_utts = int(lengths.sum()), len(signals)
+        if feed is None or feed.slot_samples < need_samples or feed.slot_utts < need_utts:
+            if feed is not None:
+                feed.close()
+            # room for what the post-processors make of a row (Deltas: (K + 1) C columns): tried on a few zero rows
+            try:
+                probe, _ = self._postprocess(torch.randn((64, C), device="cuda"), np.asarray([0, 64], dtype=np.int64))
+                widen = -(-probe.numel() // (64 * C))
+            except Exception:  # (a post-processor that wants more rows than the probe has)
+                widen = 4
+            feed = self._feeds[key] = HostFeed(comp, dtype, slot_samples=max(need_samples, 1 << 22), slot_utts=max(need_utts, 64),
+                                               slots=2, copy_threads=min(8, os.cpu_count() or 1), feature_cols=widen * C + C)
+        out_rows = {}
+
+        def post(feats, row_offsets):
+            feats, rows = self._postprocess(feats, np.asarray(row_offsets, dtype=np.int64))
+            out_rows["rows"] = rows
+            return feats
+
+        ticket = feed.submit(signals, self.pre[0].coeff if self.pre else 0.0, post=post)
+        feats, _ = feed.collect(ticket, copy=True)
+        feats = torch.from_numpy(feats)
+        rows = out_rows["rows"]
         return [feats[rows[b] : rows[b + 1]].clone() for b in range(len(signals))]
 
     def _postprocess(self, feats, rows):

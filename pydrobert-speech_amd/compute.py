@@ -11,6 +11,7 @@ MI355X; there is no CPU path in this module.
 """
 import abc
 import ctypes
+import os
 from typing import List, Mapping, Optional, Sequence, Tuple, Union
 
 import numpy as np
@@ -31,6 +32,11 @@ __all__ = [
 ]
 
 _MAX_UTTS_PER_CALL = 65535  # grid.y limit of the batch kernels
+# compute_full_batch of host signals: staging slots of the pinned ring (feed.HostFeed) and the batch size from which
+# it is used
+_FEED_SLOT_SAMPLES = 1 << 24
+_FEED_SLOT_UTTS = 4096
+_FEED_MIN_SAMPLES = 1 << 22
 
 
 class FrameComputer(AliasedFactory):
@@ -310,6 +316,7 @@ class ShortTimeFourierTransformFrameComputer(LinearFilterBankFrameComputer):
             self._filt_start_idxs, self._truncated_filts, self._dft_size, self._real, self._power
         )
         self._plans = {}  # device index -> _NativePlan (tables live on one GPU)
+        self._feeds = {}  # (device index, sample dtype) -> feed.HostFeed of compute_full_batch
         self._reset_stream()
 
     # ---- properties ---------------------------------------------------------------
@@ -739,6 +746,56 @@ class ShortTimeFourierTransformFrameComputer(LinearFilterBankFrameComputer):
             raise ValueError("signal must be 1-dimensional")
         return self._run_host_signal(signal, self.num_frames(len(signal)), None)
 
+    def _full_batch_through_feed(self, signals, lengths, in_dtype, preemphasis):
+        """Host signals through the pinned staging ring (``feed.HostFeed``): slot-sized pieces of the batch upload,
+        compute and download concurrently instead of one concatenate + pageable copy each way (measured 3 x the
+        rate on 1024 x 10 s).  Float32 signals (float64 ones when the configuration asks for float32 arithmetic)
+        of a plan with a fused kernel, batches of at least a few seconds of audio; else ``None``: the plain path."""
+        from .feed import HostFeed  # (imports this module)
+
+        torch = _native.require_device()
+        total = int(sum(lengths))
+        f64 = in_dtype == np.float64 and config.FLOAT64_ARITHMETIC == "float32"
+        if not config.HOST_FEED or total < _FEED_MIN_SAMPLES or not (in_dtype == np.float32 or f64):
+            return None
+        if max(lengths) > _FEED_SLOT_SAMPLES:
+            return None
+        plan = self._native_plan()
+        if not plan.kernel_kind or (f64 and not plan.has_f64in):
+            return None
+        key = (torch.cuda.current_device(), np.dtype(in_dtype))
+        feed = self._feeds.get(key)
+        if feed is None:
+            feed = self._feeds[key] = HostFeed(self, in_dtype, slot_samples=_FEED_SLOT_SAMPLES, slot_utts=_FEED_SLOT_UTTS,
+                                               slots=3, copy_threads=min(16, os.cpu_count() or 1))
+        # slot-sized runs of consecutive utterances
+        pieces, lo, acc = [], 0, 0
+        for b, n in enumerate(lengths):
+            if b > lo and (acc + n > _FEED_SLOT_SAMPLES or b - lo >= _FEED_SLOT_UTTS):
+                pieces.append((lo, b))
+                lo, acc = b, 0
+            acc += n
+        pieces.append((lo, len(lengths)))
+        rows = np.zeros(len(lengths) + 1, dtype=np.int64)
+        np.cumsum([self.num_frames(n) for n in lengths], out=rows[1:])
+        C = self.num_coeffs
+        out = np.empty((int(rows[-1]), C), dtype=np.float32)
+        pending = []
+
+        def drain():
+            ticket, (a, _) = pending.pop(0)
+            feed.collect_into(ticket, out[rows[a]:])
+
+        for piece in pieces:
+            if len(pending) >= feed.slots - 1:
+                drain()
+            pending.append((feed.submit(signals[piece[0] : piece[1]], preemphasis), piece))
+        while pending:
+            drain()
+        if out.dtype != in_dtype:
+            out = out.astype(in_dtype)
+        return [out[rows[b] : rows[b + 1]] for b in range(len(lengths))]
+
     def compute_full_batch(self, signals: Sequence, preemphasis: float = 0.0) -> list:
         """:func:`compute_full` of many signals in one launch (optionally pre-emphasised)
 
@@ -762,6 +819,9 @@ class ShortTimeFourierTransformFrameComputer(LinearFilterBankFrameComputer):
                 raise TypeError("GPU signals must be float32 or float64")
         else:
             in_dtype = np.asarray(signals[0]).dtype
+            through_feed = self._full_batch_through_feed(signals, lengths, in_dtype, preemphasis)
+            if through_feed is not None:
+                return through_feed
             host = np.concatenate(
                 [np.asarray(s, dtype=self._compute_dtype(in_dtype)).reshape(-1) for s in signals]
             ) if offsets[-1] else np.zeros(0, self._compute_dtype(in_dtype))

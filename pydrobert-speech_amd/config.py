@@ -5,7 +5,7 @@ global at call time, compute.py:397,459; a plan snapshots it -- change the value
 build a new computer).  `EFFECTIVE_SUPPORT_THRESHOLD` is read when a bank is built.
 """
 
-__all__ = ["EFFECTIVE_SUPPORT_THRESHOLD", "FLOAT64_ARITHMETIC", "LOG_FLOOR_VALUE", "USE_FFTPACK"]
+__all__ = ["EFFECTIVE_SUPPORT_THRESHOLD", "FLOAT64_ARITHMETIC", "HOST_FEED", "LOG_FLOOR_VALUE", "USE_FFTPACK"]
 
 #: kept for API compatibility; the DFT is always computed on the GPU here
 USE_FFTPACK: bool = False
@@ -30,3 +30,9 @@ FLOAT64_ARITHMETIC: str = "float64"
 #: waves walk contiguous stretches of the existing frames (``pds_stft_batch_ragged_f32``) -- same values, +9 %
 #: on lengths uniform in 1 ... 15 s.  ``False`` (or PDS_RAGGED_SCHEDULING=0 in the environment) keeps the plain launch (A/B runs).
 RAGGED_SCHEDULING = __import__("os").environ.get("PDS_RAGGED_SCHEDULING", "1") != "0"
+
+#: ``compute_full_batch`` of HOST signals (numpy arrays) goes through the pinned staging ring of ``feed.HostFeed``
+#: (slot-sized pieces of the batch upload, compute and download concurrently: 3 x the rate of one concatenate and one
+#: pageable copy each way) once the batch holds a few seconds of audio.  The ring keeps ~0.5 GB of pinned host
+#: memory per computer and sample dtype.  ``False`` (or PDS_HOST_FEED=0): always the plain path.
+HOST_FEED = __import__("os").environ.get("PDS_HOST_FEED", "1") != "0"

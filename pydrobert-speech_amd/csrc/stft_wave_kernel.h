@@ -2124,7 +2124,7 @@ int32_t launch_wave(const pds_stft_plan *plan, const BatchArgs &a) {
   // SIMD and is not bound by the vector pipe: +2.7 %, profiles/r3j_prefetch_n1024_ab.txt; the 128-register geometry
   // and the other walks, where it measured -4 % / +-0, with -DPDS_EXPERIMENTS=1 only)
   constexpr bool PF_PRODUCT = N1 == 64 && N2 == 16;
-  constexpr bool PF_MSEG = false;  // (superseded: the matrix-pipe launches of this geometry run three waves per SIMD instead, MSEG3)
+  [[maybe_unused]] constexpr bool PF_MSEG = false;  // (superseded: the matrix-pipe launches of this geometry run three waves per SIMD instead, MSEG3)
   // the matrix-pipe walk at N = 1024: launch bounds of three waves per SIMD (149 - 161 VGPRs), up to twelve waves per CU
   constexpr bool MSEG3 = N1 == 64 && N2 == 16;
   constexpr int MS_WAVES = MSEG3 ? 12 : 4 * MINW, MS_MINW = MSEG3 ? 3 : MINW;

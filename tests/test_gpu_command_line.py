@@ -153,3 +153,46 @@ def test_short_integration_computer_config(tmp_path, with_preemph):
         want = comp.compute_full(Preemphasize(0.9).apply(x) if with_preemph else x)
         assert got.shape == want.shape, utt
         assert np.allclose(got, want, rtol=2e-4, atol=2e-4), (utt, np.abs(got - want).max())
+
+
+def test_pcm_files_travel_as_int16_through_the_staging_ring(tmp_path, monkeypatch):
+    """A corpus of 16-bit WAV files: the samples stay int16 on the host and over PCIe (feed.HostFeed with int16
+    slots, pds_stft_batch_i16in), and the feature files equal those of the float32 pipeline"""
+    import torch
+
+    from pydrobert_speech_amd import feed as feed_mod
+
+    rng = np.random.default_rng(8)
+    root = str(tmp_path)
+    sigs, lines = {}, []
+    for i, n in enumerate((16000, 7001, 12345, 640, 30000)):
+        x = (rng.standard_normal(n) * 3000).astype("<i2")
+        p = os.path.join(root, f"u{i}.wav")
+        with wave.open(p, "wb") as fh:
+            fh.setnchannels(1), fh.setsampwidth(2), fh.setframerate(16000)
+            fh.writeframes(x.tobytes())
+        sigs[f"u{i}"] = x
+        lines.append(f"u{i} {p}")
+    map_path = os.path.join(root, "map.txt")
+    with open(map_path, "w") as fh:
+        fh.write("\n".join(lines) + "\n")
+    made = []
+    real_init = feed_mod.HostFeed.__init__
+
+    def spy(self, computer, dtype=np.float32, **kwargs):
+        made.append(np.dtype(dtype))
+        real_init(self, computer, dtype, **kwargs)
+
+    monkeypatch.setattr(feed_mod.HostFeed, "__init__", spy)
+    out = str(tmp_path / "feats")
+    rc = signals_to_torch_feat_dir([
+        map_path, json.dumps(FBANK), out, "--preprocess", json.dumps([{"name": "preemph", "coeff": 0.97}]),
+        "--postprocess", json.dumps([{"name": "deltas", "num_deltas": 2}]), "--batch-utts", "2",
+    ])
+    assert rc == 0 and made and all(d == np.int16 for d in made)
+    comp = alias_factory_subclass_from_arg(FrameComputer, dict(FBANK))
+    for utt, x in sigs.items():
+        got = torch.load(os.path.join(out, f"{utt}.pt"), weights_only=True).numpy()
+        want = Deltas(2).apply(comp.compute_full(Preemphasize(0.97).apply(x.astype("f4"))), axis=-1)
+        assert got.shape == want.shape, utt
+        assert np.allclose(got, want, rtol=2e-4, atol=2e-4), (utt, np.abs(got - want).max())

@@ -1,0 +1,134 @@
+"""The host feed (pds_feed_*, csrc/feed.hip, pydrobert_speech_amd.feed.HostFeed): batches of host signals through
+the staging ring give the features of the packed launch on the same samples -- for every sample format, ragged
+batches, more batches than slots, a post-processor on the slot's stream -- and of the oracle."""
+import json
+
+import numpy as np
+import pytest
+
+from oracle import stft_oracle as orc
+from pydrobert_speech_amd.alias import alias_factory_subclass_from_arg
+from pydrobert_speech_amd.compute import FrameComputer
+from pydrobert_speech_amd.feed import HostFeed
+from tests.conftest import assert_features_close, oracle_params
+
+pytestmark = pytest.mark.gpu
+F32 = dict(rtol=1e-4, atol=1e-5)
+
+
+def build(cfg):
+    return alias_factory_subclass_from_arg(FrameComputer, json.loads(json.dumps(cfg)))
+
+
+def batches_of(rng, dtype, count, utts, top):
+    out = []
+    for _ in range(count):
+        lens = rng.integers(0, top, size=utts)
+        if np.dtype(dtype) == np.int16:
+            out.append([rng.integers(-20000, 20000, size=n).astype(np.int16) for n in lens])
+        else:
+            out.append([(3000 * rng.standard_normal(n)).astype(dtype) for n in lens])
+    return out
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64, np.int16], ids=["f32", "f64", "i16"])
+def test_feed_matches_the_packed_launch_and_the_oracle(dtype, golden_meta, golden_tables, monkeypatch):
+    import torch
+
+    from pydrobert_speech_amd import config
+
+    name = "c2_tri_mel40"
+    comp = build(golden_meta["configs"][name])
+    p = oracle_params(golden_tables, name)
+    rng = np.random.default_rng(11)
+    batches = batches_of(rng, dtype, 7, 9, 6000)  # more batches than slots: the ring wraps twice
+    batches[3] = []  # (an empty batch passes through)
+    batches[4] = [b[:0] for b in batches[4]]  # (... and one of empty utterances)
+    monkeypatch.setattr(config, "FLOAT64_ARITHMETIC", "float32")
+    with HostFeed(comp, dtype, slot_samples=60000, slot_utts=16, slots=3, copy_threads=3) as feed:
+        got = list(feed.run(batches))
+    assert len(got) == len(batches)
+    for batch, feats in zip(batches, got):
+        assert len(feats) == len(batch)
+        if not batch:
+            continue
+        lens = [len(x) for x in batch]
+        offs = np.concatenate([[0], np.cumsum(lens)[:-1]])
+        packed = torch.from_numpy(np.concatenate(batch)).cuda()
+        out32 = torch.empty((sum(comp.num_frames(n) for n in lens), comp.num_coeffs), dtype=torch.float32, device="cuda")
+        want, rows = comp.compute_packed(packed, offs, lens, out=out32 if np.dtype(dtype) == np.float64 else None)
+        want = want.cpu().numpy()
+        for b, x in enumerate(batch):
+            assert feats[b].dtype == np.float32
+            np.testing.assert_array_equal(feats[b], want[rows[b] : rows[b + 1]])
+            assert_features_close(feats[b], orc.compute_full(x.astype(np.float64), p), what=(b, len(x)), **F32)
+
+
+def test_feed_with_preemphasis_and_a_post_processor_on_the_slot_stream(golden_meta, golden_tables):
+    import torch
+
+    from pydrobert_speech_amd.post import Deltas
+
+    name = "c3_fbank80_energy"
+    comp = build(golden_meta["configs"][name])
+    deltas = Deltas(2)
+    rng = np.random.default_rng(12)
+    batches = batches_of(rng, np.float32, 4, 5, 9000)
+    C = comp.num_coeffs
+
+    def post(feats, row_offsets):
+        out = torch.empty((feats.shape[0], 3 * C), dtype=torch.float32, device=feats.device)
+        out[:, :C] = feats
+        return deltas.apply_rows(out[:, :C], row_offsets, out=out)
+
+    with HostFeed(comp, np.float32, slot_samples=50000, slot_utts=8, slots=2, feature_cols=3 * C) as feed:
+        got = list(feed.run(batches, preemphasis=0.97, post=post))
+    for batch, feats in zip(batches, got):
+        lens = [len(x) for x in batch]
+        offs = np.concatenate([[0], np.cumsum(lens)[:-1]])
+        packed = torch.from_numpy(np.concatenate(batch)).cuda()
+        layout = comp.prepare_layout(offs, lens, device=packed.device)
+        want = comp.launch_with_deltas(packed, layout, deltas, fused=False, preemphasis=0.97).cpu().numpy()
+        rows = layout.row_offsets
+        for b in range(len(batch)):
+            assert feats[b].shape == (rows[b + 1] - rows[b], 3 * C)
+            np.testing.assert_array_equal(feats[b], want[rows[b] : rows[b + 1]])
+
+
+def test_feed_refuses_what_does_not_fit_and_misuse(golden_meta):
+    comp = build(golden_meta["configs"]["c2_tri_mel40"])
+    with HostFeed(comp, np.float32, slot_samples=1000, slot_utts=2, slots=2) as feed:
+        with pytest.raises(ValueError):
+            feed.submit([np.zeros(600, np.float32), np.zeros(600, np.float32)])  # too many samples
+    with HostFeed(comp, np.float32, slot_samples=1000, slot_utts=2, slots=2) as feed:
+        with pytest.raises(ValueError):
+            feed.submit([np.zeros(10, np.float32)] * 3)  # too many utterances
+    with pytest.raises(TypeError):
+        HostFeed(comp, np.int32)
+    # a transform size without a fused int16-input kernel: refused at creation, not at the first batch
+    nopad = build({"name": "stft", "bank": {"name": "fbank", "num_filts": 40}, "frame_length_ms": 25,
+                   "frame_shift_ms": 10, "pad_to_nearest_power_of_two": False})
+    with pytest.raises(ValueError):
+        HostFeed(nopad, np.int16)
+
+
+def test_compute_full_batch_of_host_signals_goes_through_the_feed(golden_meta, monkeypatch):
+    """compute_full_batch of numpy signals: above a few seconds of audio the batch streams through the staging
+    ring in slot-sized pieces -- same values as the plain path (config.HOST_FEED = False), bit for bit"""
+    from pydrobert_speech_amd import compute, config
+
+    comp = build(golden_meta["configs"]["c2_tri_mel40"])
+    rng = np.random.default_rng(13)
+    lens = rng.integers(1000, 60000, size=40)
+    sigs = [(3000 * rng.standard_normal(n)).astype(np.float32) for n in lens]
+    monkeypatch.setattr(compute, "_FEED_MIN_SAMPLES", 100000)
+    monkeypatch.setattr(compute, "_FEED_SLOT_SAMPLES", 150000)  # (several pieces: the ring wraps)
+    monkeypatch.setattr(compute, "_FEED_SLOT_UTTS", 7)
+    got = comp.compute_full_batch(sigs, preemphasis=0.97)
+    assert comp._feeds, "the batch did not go through the feed"
+    monkeypatch.setattr(config, "HOST_FEED", False)
+    want = comp.compute_full_batch(sigs, preemphasis=0.97)
+    assert len(got) == len(want) == len(sigs)
+    for g, w in zip(got, want):
+        assert g.dtype == w.dtype == np.float32
+        np.testing.assert_array_equal(g, w)
