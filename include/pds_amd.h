@@ -271,6 +271,14 @@ int32_t pds_feed_create(const pds_stft_plan *plan, int32_t sample_format, int64_
                         int32_t slots, int32_t feature_cols, pds_feed **feed_out);
 void pds_feed_destroy(pds_feed *feed);
 int64_t pds_feed_slot_rows(const pds_feed *feed);
+/* direct != 0 (the default for float32 and int16 samples): the kernel reads the samples from the slot's pinned host buffer and writes the features
+ * to its pinned host buffer itself, so upload and download run concurrently, driven by the kernel's own loads and
+ * stores (with download = 0 in pds_feed_submit the features stay in device memory for the post-processors);
+ * direct = 0 (the default for float64 samples): staged -- DMA upload into device memory, kernel, DMA download.
+ * Measured on 1024 x 10 s at 16 kHz: int16 samples 6.4 ms direct against 8.8 ms staged, float32 13.9 against 14.5
+ * (the two DMA directions take turns on the measured platform), float64 29.9 against 26.3 (the kernel's 16-byte pair
+ * loads do worse over the link than the DMA engine).  Not while a batch is in flight. */
+int32_t pds_feed_set_direct(pds_feed *feed, int32_t direct);
 int32_t pds_feed_acquire(pds_feed *feed, int32_t *slot_out, void **h_samples_out);
 int32_t pds_feed_pack(pds_feed *feed, int32_t slot, const void *const *signals, const int64_t *lengths, int32_t n_utts,
                       int32_t threads);

@@ -159,6 +159,7 @@ SIGNATURES = {
     "pds_feed_create": (c_int32, [c_void_p, c_int32, c_int64, c_int32, c_int32, c_int32, POINTER(c_void_p)]),
     "pds_feed_destroy": (None, [c_void_p]),
     "pds_feed_slot_rows": (c_int64, [c_void_p]),
+    "pds_feed_set_direct": (c_int32, [c_void_p, c_int32]),
     "pds_feed_acquire": (c_int32, [c_void_p, POINTER(c_int32), POINTER(c_void_p)]),
     "pds_feed_pack": (c_int32, [c_void_p, c_int32, c_void_p, c_void_p, c_int32, c_int32]),
     "pds_feed_submit": (c_int32, [c_void_p, c_int32, c_void_p, c_int32, c_double, c_int32]),

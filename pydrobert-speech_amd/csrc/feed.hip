@@ -28,6 +28,8 @@ struct Slot {
   int64_t *d_work = nullptr;     // [min(slot_utts, 65535) + 1] chunk prefix sums of the ragged launch
   float *d_feats = nullptr;      // slot_rows * out_cols
   float *h_feats = nullptr;      // pinned
+  void *hd_samples = nullptr;    // the pinned buffers as the device addresses them (direct mode)
+  float *hd_feats = nullptr;
   hipStream_t stream = nullptr;
   hipEvent_t done = nullptr;
   int state = FREE;
@@ -46,6 +48,11 @@ struct pds_feed {
   std::mutex mu;
   std::condition_variable cv;
   int next_acquire = 0;
+  // direct mode: the kernel reads the samples from the pinned host buffer and writes the features to the pinned host
+  // buffer itself -- upload and download then run concurrently, driven by the kernel's own loads and stores, where
+  // the two DMA copies of the staged mode take turns on this platform (tools/pcie_overlap.py, tools/zero_copy_probe.py:
+  // int16 samples 9.0 -> 6.4 ms per 1024 x 10 s batch, float32 14.7 -> 13.8 ms)
+  bool direct = true;
 };
 
 namespace {
@@ -80,6 +87,8 @@ int32_t build_slot(pds_feed *f, Slot &s) {
   PDS_HIP(hipMalloc((void **)&s.d_work, ((size_t)std::min<int32_t>(f->slot_utts, 65535) + 1) * sizeof(int64_t)));
   PDS_HIP(hipMalloc((void **)&s.d_feats, fb));
   PDS_HIP(hipHostMalloc((void **)&s.h_feats, fb, hipHostMallocDefault));
+  PDS_HIP(hipHostGetDevicePointer(&s.hd_samples, s.h_samples, 0));
+  PDS_HIP(hipHostGetDevicePointer((void **)&s.hd_feats, s.h_feats, 0));
   PDS_HIP(hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking));
   PDS_HIP(hipEventCreateWithFlags(&s.done, hipEventDisableTiming));
   s.h_rows = new int64_t[(size_t)f->slot_utts + 1];
@@ -115,6 +124,9 @@ int32_t pds_feed_create(const pds_stft_plan *plan, int32_t sample_format, int64_
   f->num_slots = slots;
   f->out_cols = pds_stft_num_coeffs(plan);
   f->feature_cols = std::max(feature_cols, f->out_cols);
+  // (float64 samples: the kernel's 16-byte pair loads do worse over the link than the DMA engine -- 29.9 against
+  // 26.3 ms per 1024 x 10 s batch -- so they are staged by default)
+  f->direct = sample_format != PDS_SAMPLES_F64;
   // rows a slot can hold: an utterance of n samples yields at most (n + S / 2) / S <= n / S + 1 frames
   f->slot_rows = slot_samples / plan->d.frame_shift + slot_utts;
   f->slots.resize(slots);
@@ -140,6 +152,15 @@ void pds_feed_destroy(pds_feed *f) {
 }
 
 int64_t pds_feed_slot_rows(const pds_feed *f) { return f ? f->slot_rows : 0; }
+
+int32_t pds_feed_set_direct(pds_feed *f, int32_t direct) {
+  if (!f) return fail("feed_set_direct: null feed");
+  std::lock_guard<std::mutex> lk(f->mu);
+  for (const Slot &s : f->slots)
+    if (s.state == ACQUIRED || s.state == SUBMITTED) return fail("feed_set_direct: a batch is in flight");
+  f->direct = direct != 0;
+  return PDS_OK;
+}
 
 int32_t pds_feed_acquire(pds_feed *f, int32_t *slot_out, void **h_samples_out) {
   if (!f || !slot_out || !h_samples_out) return fail("feed_acquire: null argument");
@@ -226,7 +247,10 @@ int32_t pds_feed_submit(pds_feed *f, int32_t slot, const int64_t *lengths, int32
   s.n_utts = n_utts;
   s.rows = rows;
   s.samples = samples;
-  if (samples > 0) PDS_HIP(hipMemcpyAsync(s.d_samples, s.h_samples, (size_t)samples * f->sample_bytes, hipMemcpyHostToDevice, s.stream));
+  const void *sig = f->direct ? s.hd_samples : s.d_samples;
+  float *feat = (f->direct && download) ? s.hd_feats : s.d_feats;
+  if (!f->direct && samples > 0)
+    PDS_HIP(hipMemcpyAsync(s.d_samples, s.h_samples, (size_t)samples * f->sample_bytes, hipMemcpyHostToDevice, s.stream));
   if (B > 0) PDS_HIP(hipMemcpyAsync(s.d_index, s.h_index, (size_t)4 * SU * sizeof(int64_t), hipMemcpyHostToDevice, s.stream));
   // a batch whose utterances differ in length: stretch scheduling over the chunks that exist (float32 samples)
   const bool ragged = f->format == PDS_SAMPLES_F32 && preemph == 0.0 && B > 0 && longest > 0 &&
@@ -238,21 +262,21 @@ int32_t pds_feed_submit(pds_feed *f, int32_t slot, const int64_t *lengths, int32
     const int64_t *d_off = s.d_index + lo, *d_len = s.d_index + SU + lo, *d_nfr = s.d_index + 2 * SU + lo, *d_row = s.d_index + 3 * SU + lo;
     int32_t rc;
     if (f->format == PDS_SAMPLES_F64)
-      rc = pds_stft_batch_f64in(f->plan, (const double *)s.d_samples, d_off, d_len, d_nfr, d_row, nb, mx, -1, preemph, s.d_feats, 0,
+      rc = pds_stft_batch_f64in(f->plan, (const double *)sig, d_off, d_len, d_nfr, d_row, nb, mx, -1, preemph, feat, 0,
                                 f->out_cols, s.stream);
     else if (f->format == PDS_SAMPLES_I16)
-      rc = pds_stft_batch_i16in(f->plan, (const int16_t *)s.d_samples, d_off, d_len, d_nfr, d_row, nb, mx, -1, preemph, s.d_feats,
+      rc = pds_stft_batch_i16in(f->plan, (const int16_t *)sig, d_off, d_len, d_nfr, d_row, nb, mx, -1, preemph, feat,
                                 f->out_cols, s.stream);
     else if (ragged)
-      rc = pds_stft_batch_ragged_f32(f->plan, (const float *)s.d_samples, d_off, d_len, d_nfr, d_row, nb, mx, -1, preemph, s.d_work,
-                                     s.d_feats, f->out_cols, s.stream);
+      rc = pds_stft_batch_ragged_f32(f->plan, (const float *)sig, d_off, d_len, d_nfr, d_row, nb, mx, -1, preemph, s.d_work,
+                                     feat, f->out_cols, s.stream);
     else
-      rc = pds_stft_batch_f32(f->plan, (const float *)s.d_samples, d_off, d_len, d_nfr, d_row, nb, mx, -1, preemph, s.d_feats,
+      rc = pds_stft_batch_f32(f->plan, (const float *)sig, d_off, d_len, d_nfr, d_row, nb, mx, -1, preemph, feat,
                               f->out_cols, s.stream);
     if (rc != PDS_OK) return rc;
   }
   if (download) {
-    if (rows > 0)
+    if (rows > 0 && !f->direct)
       PDS_HIP(hipMemcpyAsync(s.h_feats, s.d_feats, (size_t)rows * f->out_cols * sizeof(float), hipMemcpyDeviceToHost, s.stream));
     PDS_HIP(hipEventRecord(s.done, s.stream));
   }

@@ -40,11 +40,15 @@ class HostFeed:
     a frame is loaded).  `slot_samples` / `slot_utts`: capacity of one batch.  `slots`: depth of the ring
     (3 keeps the three engines busy).  `copy_threads`: host threads that copy a batch into its staging buffer.
     `feature_cols`: float32 columns per row the slots' feature buffers have room for (default ``num_coeffs``;
-    more when a `post` callable widens the rows).  Features are float32.
+    more when a `post` callable widens the rows).  `direct`: ``True`` -- the kernel reads the samples from the
+    pinned host buffer and writes the features to the pinned host buffer itself, so upload and download run
+    concurrently (int16: 160 M frames/s host to host against 117 M staged); ``False`` -- DMA copies either side of
+    the kernel; ``None`` (default) -- direct for float32 and int16 samples, staged for float64 (where it measured
+    faster).  Features are float32.
     """
 
     def __init__(self, computer, dtype=np.float32, slot_samples: int = 1 << 26, slot_utts: int = 1024, slots: int = 3,
-                 copy_threads: int = 8, device=None, feature_cols: int = 0):
+                 copy_threads: int = 8, device=None, feature_cols: int = 0, direct: Optional[bool] = None):
         torch = _native.require_device()
         self._lib = _native.lib()
         self.dtype = np.dtype(dtype)
@@ -62,6 +66,8 @@ class HostFeed:
                                                     self.slot_utts, self.slots, int(feature_cols), ctypes.byref(handle)),
                           "pds_feed_create")
         self.feature_cols = max(int(feature_cols), self.num_coeffs)
+        self.direct = (self.dtype != np.float64) if direct is None else bool(direct)
+        _native.check(self._lib.pds_feed_set_direct(handle, int(self.direct)), "pds_feed_set_direct")
         self._handle = handle
         self.slot_rows = int(self._lib.pds_feed_slot_rows(handle))
         self._torch = torch

@@ -31,8 +31,9 @@ def batches_of(rng, dtype, count, utts, top):
     return out
 
 
+@pytest.mark.parametrize("direct", [True, False], ids=["direct", "staged"])
 @pytest.mark.parametrize("dtype", [np.float32, np.float64, np.int16], ids=["f32", "f64", "i16"])
-def test_feed_matches_the_packed_launch_and_the_oracle(dtype, golden_meta, golden_tables, monkeypatch):
+def test_feed_matches_the_packed_launch_and_the_oracle(dtype, direct, golden_meta, golden_tables, monkeypatch):
     import torch
 
     from pydrobert_speech_amd import config
@@ -45,7 +46,7 @@ def test_feed_matches_the_packed_launch_and_the_oracle(dtype, golden_meta, golde
     batches[3] = []  # (an empty batch passes through)
     batches[4] = [b[:0] for b in batches[4]]  # (... and one of empty utterances)
     monkeypatch.setattr(config, "FLOAT64_ARITHMETIC", "float32")
-    with HostFeed(comp, dtype, slot_samples=60000, slot_utts=16, slots=3, copy_threads=3) as feed:
+    with HostFeed(comp, dtype, slot_samples=60000, slot_utts=16, slots=3, copy_threads=3, direct=direct) as feed:
         got = list(feed.run(batches))
     assert len(got) == len(batches)
     for batch, feats in zip(batches, got):
@@ -64,7 +65,8 @@ def test_feed_matches_the_packed_launch_and_the_oracle(dtype, golden_meta, golde
             assert_features_close(feats[b], orc.compute_full(x.astype(np.float64), p), what=(b, len(x)), **F32)
 
 
-def test_feed_with_preemphasis_and_a_post_processor_on_the_slot_stream(golden_meta, golden_tables):
+@pytest.mark.parametrize("direct", [True, False], ids=["direct", "staged"])
+def test_feed_with_preemphasis_and_a_post_processor_on_the_slot_stream(direct, golden_meta, golden_tables):
     import torch
 
     from pydrobert_speech_amd.post import Deltas
@@ -81,7 +83,7 @@ def test_feed_with_preemphasis_and_a_post_processor_on_the_slot_stream(golden_me
         out[:, :C] = feats
         return deltas.apply_rows(out[:, :C], row_offsets, out=out)
 
-    with HostFeed(comp, np.float32, slot_samples=50000, slot_utts=8, slots=2, feature_cols=3 * C) as feed:
+    with HostFeed(comp, np.float32, slot_samples=50000, slot_utts=8, slots=2, feature_cols=3 * C, direct=direct) as feed:
         got = list(feed.run(batches, preemphasis=0.97, post=post))
     for batch, feats in zip(batches, got):
         lens = [len(x) for x in batch]

@@ -65,16 +65,18 @@ for trial in range(2):
     dt = time.perf_counter() - t0
 report("one pinned buffer, upload + launch + download in turn, float32", dt, nb, 4)
 
-for dtype, in_bytes in ((np.float32, 4), (np.float64, 8), (np.int16, 2)):
+for dtype, in_bytes, direct in ((np.float32, 4, False), (np.float32, 4, True), (np.float64, 8, False), (np.float64, 8, True),
+                                (np.int16, 2, False), (np.int16, 2, True)):
     data = base.astype(dtype) if dtype != np.int16 else np.clip(base, -32768, 32767).astype(np.int16)
     sigs = [data[i * n : (i + 1) * n] for i in range(B)]
-    with HostFeed(comp, dtype, slot_samples=B * n, slot_utts=B, slots=3, copy_threads=16) as feed:
-        for _ in feed.run([sigs] * 3):
+    mode = "direct" if direct else "staged"
+    with HostFeed(comp, dtype, slot_samples=B * n, slot_utts=B, slots=3, copy_threads=16, direct=direct) as feed:
+        for _ in feed.run([sigs] * 3, copy=False):
             pass
         t0 = time.perf_counter()
-        for feats in feed.run([sigs] * nb):
+        for feats in feed.run([sigs] * nb, copy=False):
             pass
-        report(f"host feed, {np.dtype(dtype).name} samples, pageable numpy in (copy_threads=16)", time.perf_counter() - t0, nb, in_bytes)
+        report(f"host feed ({mode}), {np.dtype(dtype).name} samples, pageable numpy in (16 copy threads)", time.perf_counter() - t0, nb, in_bytes)
         # the caller's readers write into the staging buffer themselves: no copy in front of the upload
         lengths = np.full(B, n, dtype=np.int64)
         lib, handle = feed._lib, feed._handle
@@ -93,6 +95,6 @@ for dtype, in_bytes in ((np.float32, 4), (np.float64, 8), (np.int16, 2)):
             while pending:
                 got, rows = feed.collect(pending.pop(0), copy=False)
             dt = time.perf_counter() - t0
-        report(f"host feed, {np.dtype(dtype).name} samples, staging buffer filled by the caller", dt, nb, in_bytes)
+        report(f"host feed ({mode}), {np.dtype(dtype).name} samples, staging buffer filled by the caller", dt, nb, in_bytes)
         ref = comp.compute_packed(torch.from_numpy(data).cuda(), np.arange(B) * n, np.full(B, n))[0].float().cpu().numpy()
         assert np.array_equal(got, ref), "feed result differs from the packed launch"
