@@ -240,7 +240,9 @@ int32_t pds_stft_batch_f32_generic(const pds_stft_plan *plan, const float *d_sig
  * A feed is a ring of `slots` staging slots on the current device -- pinned host buffers for samples and
  * features, their device twins, one stream each -- so that batch k + 1 uploads while batch k computes and
  * batch k - 1 downloads.  Samples travel as they are stored (PDS_SAMPLES_I16: 2 bytes per sample, converted as
- * a frame is loaded; PDS_SAMPLES_F64: the reference drivers' float64, rounded as a frame is loaded).
+ * a frame is loaded; PDS_SAMPLES_F64: the reference drivers' float64, rounded as a frame is loaded; a plan whose
+ * launch does not serve the format -- no fused kernel for the transform size, a filter table too large for LDS --
+ * gets its samples widened to float32 by a device pass in front of the float32 launch instead).
  *
  *   pds_feed_acquire  the ring's next slot (blocks until its previous batch was released) and the pinned host
  *                     buffer the caller -- its reader threads -- fills with the batch's utterances back to back

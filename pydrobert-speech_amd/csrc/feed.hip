@@ -27,6 +27,8 @@ struct Slot {
   int64_t *h_rows = nullptr;     // host (not pinned), [slot_utts + 1] row offsets handed to the caller
   int64_t *d_work = nullptr;     // [min(slot_utts, 65535) + 1] chunk prefix sums of the ragged launch
   float *d_feats = nullptr;      // slot_rows * out_cols
+  float *d_wide = nullptr;       // slot_samples float32: the samples widened on the device (plans whose launch does
+                                 // not serve the slot's sample format, see pds_feed_submit); allocated on first use
   float *h_feats = nullptr;      // pinned
   void *hd_samples = nullptr;    // the pinned buffers as the device addresses them (direct mode)
   float *hd_feats = nullptr;
@@ -53,9 +55,17 @@ struct pds_feed {
   // the two DMA copies of the staged mode take turns on this platform (tools/pcie_overlap.py, tools/zero_copy_probe.py:
   // int16 samples 9.0 -> 6.4 ms per 1024 x 10 s batch, float32 14.7 -> 13.8 ms)
   bool direct = true;
+  // the plan's launch refused the slots' sample format (a filter table too large for LDS beside the waves' areas):
+  // samples are widened to float32 by a device pass first, as compute.py::launch does for such plans
+  std::atomic<bool> widen{false};
 };
 
 namespace {
+
+template <typename T>
+__global__ __launch_bounds__(256) void widen_kernel(const T *__restrict__ in, float *__restrict__ out, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) out[i] = (float)in[i];
+}
 
 int32_t fail(const std::string &msg) {
   pds::set_error(msg);
@@ -69,6 +79,7 @@ void release_slot(Slot &s) {
   if (s.d_index) (void)hipFree(s.d_index);
   if (s.d_work) (void)hipFree(s.d_work);
   if (s.d_feats) (void)hipFree(s.d_feats);
+  if (s.d_wide) (void)hipFree(s.d_wide);
   if (s.h_feats) (void)hipHostFree(s.h_feats);
   if (s.done) (void)hipEventDestroy(s.done);
   if (s.stream) (void)hipStreamDestroy(s.stream);
@@ -106,10 +117,6 @@ int32_t pds_feed_create(const pds_stft_plan *plan, int32_t sample_format, int64_
     return fail("feed_create: sample_format must be PDS_SAMPLES_F32, PDS_SAMPLES_F64 or PDS_SAMPLES_I16");
   if (slot_samples < 1 || slot_utts < 1 || slots < 1 || slots > 16 || feature_cols < 0)
     return fail("feed_create: need slot_samples >= 1, slot_utts >= 1, 1 <= slots <= 16, feature_cols >= 0");
-  if (sample_format == PDS_SAMPLES_F64 && !pds_stft_plan_has_f64in(plan))
-    return fail("feed_create: the plan has no fused float64-input kernel (pds_stft_plan_has_f64in)");
-  if (sample_format == PDS_SAMPLES_I16 && !pds_stft_plan_has_i16in(plan))
-    return fail("feed_create: the plan has no fused int16-input kernel (pds_stft_plan_has_i16in)");
   int current = -1;
   PDS_HIP(hipGetDevice(&current));
   if (current != plan->device) return fail("feed_create: the plan lives on another device than the current one");
@@ -127,6 +134,9 @@ int32_t pds_feed_create(const pds_stft_plan *plan, int32_t sample_format, int64_
   // (float64 samples: the kernel's 16-byte pair loads do worse over the link than the DMA engine -- 29.9 against
   // 26.3 ms per 1024 x 10 s batch -- so they are staged by default)
   f->direct = sample_format != PDS_SAMPLES_F64;
+  // (transform sizes without a fused float64- / int16-input kernel: widened on the device from the first batch on)
+  f->widen.store((sample_format == PDS_SAMPLES_F64 && !pds_stft_plan_has_f64in(plan)) ||
+                 (sample_format == PDS_SAMPLES_I16 && !pds_stft_plan_has_i16in(plan)));
   // rows a slot can hold: an utterance of n samples yields at most (n + S / 2) / S <= n / S + 1 frames
   f->slot_rows = slot_samples / plan->d.frame_shift + slot_utts;
   f->slots.resize(slots);
@@ -253,27 +263,45 @@ int32_t pds_feed_submit(pds_feed *f, int32_t slot, const int64_t *lengths, int32
     PDS_HIP(hipMemcpyAsync(s.d_samples, s.h_samples, (size_t)samples * f->sample_bytes, hipMemcpyHostToDevice, s.stream));
   if (B > 0) PDS_HIP(hipMemcpyAsync(s.d_index, s.h_index, (size_t)4 * SU * sizeof(int64_t), hipMemcpyHostToDevice, s.stream));
   // a batch whose utterances differ in length: stretch scheduling over the chunks that exist (float32 samples)
-  const bool ragged = f->format == PDS_SAMPLES_F32 && preemph == 0.0 && B > 0 && longest > 0 &&
-                      (double)rows < 0.9 * (double)longest * (double)B;
-  for (int64_t lo = 0; lo < B && rows > 0; lo += 65535) {
-    const int32_t nb = (int32_t)std::min<int64_t>(65535, B - lo);
-    int64_t mx = 0;
-    for (int64_t b = lo; b < lo + nb; ++b) mx = std::max(mx, nfr[b]);
-    const int64_t *d_off = s.d_index + lo, *d_len = s.d_index + SU + lo, *d_nfr = s.d_index + 2 * SU + lo, *d_row = s.d_index + 3 * SU + lo;
-    int32_t rc;
-    if (f->format == PDS_SAMPLES_F64)
-      rc = pds_stft_batch_f64in(f->plan, (const double *)sig, d_off, d_len, d_nfr, d_row, nb, mx, -1, preemph, feat, 0,
+  const bool ragged = preemph == 0.0 && B > 0 && longest > 0 && (double)rows < 0.9 * (double)longest * (double)B;
+  for (int attempt = 0; attempt < 2; ++attempt) {
+    int32_t format = f->format;
+    const void *src = sig;
+    if (f->widen.load() && format != PDS_SAMPLES_F32 && rows > 0) {
+      if (!s.d_wide) PDS_HIP(hipMalloc((void **)&s.d_wide, (size_t)f->slot_samples * sizeof(float)));
+      const unsigned blocks = (unsigned)std::min<int64_t>((samples + 255) / 256, 256 * 32);
+      if (format == PDS_SAMPLES_F64)
+        hipLaunchKernelGGL(widen_kernel<double>, dim3(blocks), dim3(256), 0, s.stream, (const double *)sig, s.d_wide, samples);
+      else
+        hipLaunchKernelGGL(widen_kernel<int16_t>, dim3(blocks), dim3(256), 0, s.stream, (const int16_t *)sig, s.d_wide, samples);
+      PDS_HIP(hipGetLastError());
+      src = s.d_wide;
+      format = PDS_SAMPLES_F32;
+    }
+    int32_t rc = PDS_OK;
+    for (int64_t lo = 0; lo < B && rows > 0 && rc == PDS_OK; lo += 65535) {
+      const int32_t nb = (int32_t)std::min<int64_t>(65535, B - lo);
+      int64_t mx = 0;
+      for (int64_t b = lo; b < lo + nb; ++b) mx = std::max(mx, nfr[b]);
+      const int64_t *d_off = s.d_index + lo, *d_len = s.d_index + SU + lo, *d_nfr = s.d_index + 2 * SU + lo, *d_row = s.d_index + 3 * SU + lo;
+      if (format == PDS_SAMPLES_F64)
+        rc = pds_stft_batch_f64in(f->plan, (const double *)src, d_off, d_len, d_nfr, d_row, nb, mx, -1, preemph, feat, 0,
+                                  f->out_cols, s.stream);
+      else if (format == PDS_SAMPLES_I16)
+        rc = pds_stft_batch_i16in(f->plan, (const int16_t *)src, d_off, d_len, d_nfr, d_row, nb, mx, -1, preemph, feat,
+                                  f->out_cols, s.stream);
+      else if (ragged)
+        rc = pds_stft_batch_ragged_f32(f->plan, (const float *)src, d_off, d_len, d_nfr, d_row, nb, mx, -1, preemph, s.d_work,
+                                       feat, f->out_cols, s.stream);
+      else
+        rc = pds_stft_batch_f32(f->plan, (const float *)src, d_off, d_len, d_nfr, d_row, nb, mx, -1, preemph, feat,
                                 f->out_cols, s.stream);
-    else if (f->format == PDS_SAMPLES_I16)
-      rc = pds_stft_batch_i16in(f->plan, (const int16_t *)sig, d_off, d_len, d_nfr, d_row, nb, mx, -1, preemph, feat,
-                                f->out_cols, s.stream);
-    else if (ragged)
-      rc = pds_stft_batch_ragged_f32(f->plan, (const float *)sig, d_off, d_len, d_nfr, d_row, nb, mx, -1, preemph, s.d_work,
-                                     feat, f->out_cols, s.stream);
-    else
-      rc = pds_stft_batch_f32(f->plan, (const float *)sig, d_off, d_len, d_nfr, d_row, nb, mx, -1, preemph, feat,
-                              f->out_cols, s.stream);
-    if (rc != PDS_OK) return rc;
+      // (the first piece is refused before anything of it is queued: switch the feed to widened samples and start over)
+      if (rc == PDS_ERR_INVALID && lo == 0 && format != PDS_SAMPLES_F32 && attempt == 0) break;
+      if (rc != PDS_OK) return rc;
+    }
+    if (rc == PDS_OK) break;
+    f->widen.store(true);
   }
   if (download) {
     if (rows > 0 && !f->direct)

@@ -107,11 +107,32 @@ def test_feed_refuses_what_does_not_fit_and_misuse(golden_meta):
             feed.submit([np.zeros(10, np.float32)] * 3)  # too many utterances
     with pytest.raises(TypeError):
         HostFeed(comp, np.int32)
-    # a transform size without a fused int16-input kernel: refused at creation, not at the first batch
-    nopad = build({"name": "stft", "bank": {"name": "fbank", "num_filts": 40}, "frame_length_ms": 25,
-                   "frame_shift_ms": 10, "pad_to_nearest_power_of_two": False})
-    with pytest.raises(ValueError):
-        HostFeed(nopad, np.int16)
+
+
+@pytest.mark.parametrize("direct", [True, False], ids=["direct", "staged"])
+def test_feed_widens_on_the_device_where_no_kernel_takes_the_format(direct):
+    """A transform size without a fused int16-input kernel (N = L = 400), and a dense bank whose table does not
+    fit in LDS for the int16 instantiations: the feed widens the samples on the device and takes the float32 launch
+    -- the rows of compute_packed on the same samples"""
+    import torch
+
+    nopad = {"name": "stft", "bank": {"name": "fbank", "num_filts": 40}, "frame_length_ms": 25,
+             "frame_shift_ms": 10, "pad_to_nearest_power_of_two": False}
+    dense = {"name": "stft", "bank": {"name": "gammatone", "sampling_rate": 44100, "num_filts": 27, "scaling_function": "bark"},
+             "frame_length_ms": 25.0, "frame_shift_ms": 8.0, "use_power": False, "use_log": False, "kaldi_shift": True}
+    rng = np.random.default_rng(14)
+    for cfg in (nopad, dense):
+        comp = build(cfg)
+        batch = [rng.integers(-20000, 20000, size=n).astype(np.int16) for n in (5000, 1, 12000, 0, 7000)]
+        with HostFeed(comp, np.int16, slot_samples=30000, slot_utts=8, slots=2, direct=direct) as feed:
+            got = list(feed.run([batch, batch]))
+        lens = [len(x) for x in batch]
+        offs = np.concatenate([[0], np.cumsum(lens)[:-1]])
+        want, rows = comp.compute_packed(torch.from_numpy(np.concatenate(batch)).cuda(), offs, lens)
+        want = want.cpu().numpy()
+        for feats in got:
+            for b in range(len(batch)):
+                np.testing.assert_array_equal(feats[b], want[rows[b] : rows[b + 1]])
 
 
 def test_compute_full_batch_of_host_signals_goes_through_the_feed(golden_meta, monkeypatch):

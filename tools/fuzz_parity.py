@@ -253,6 +253,39 @@ def main():
                             fails += 1
                             print("FAIL f64in", "len", lens[b], msg, json.dumps(cfg))
                             break
+                # int16 PCM into the fused kernel (converted at the frame load; round 3), with and without fused
+                # pre-emphasis, against the oracle on the converted samples; every other draw through the host feed
+                # (pinned staging ring; direct and staged in turn), which must give the packed launch's rows bit for bit
+                if plan.has_i16in and rng.random() < 0.5:
+                    pcm = [np.clip(np.rint(x), -32768, 32767).astype(np.int16) for x in sigs]
+                    coeff = float(rng.choice([0.0, 0.0, 0.97]))
+                    xs = torch.from_numpy(np.concatenate(pcm)).cuda()
+                    offs = np.concatenate([[0], np.cumsum(lens)[:-1]])
+                    y16, rows16 = comp.compute_packed(xs, offs, lens, preemphasis=coeff)
+                    y16 = y16.cpu().numpy()
+                    kinds["i16in"] = kinds.get("i16in", 0) + 1
+                    tol16 = dict(rtol=2e-4, atol=2e-5) if coeff else tol
+                    for b in range(len(lens)):
+                        ref = pcm[b].astype(np.float64)
+                        w16 = orc.compute_full(orc.preemphasize(ref, coeff) if coeff else ref, p)
+                        ok, msg = close(y16[rows16[b] : rows16[b + 1]], w16, is_log=bool(comp._log), **tol16)
+                        if not ok:
+                            fails += 1
+                            print("FAIL i16in", "len", lens[b], "preemph", coeff, msg, json.dumps(cfg))
+                            break
+                    if rng.random() < 0.5:
+                        from pydrobert_speech_amd.feed import HostFeed
+
+                        direct = bool(rng.random() < 0.5)
+                        with HostFeed(comp, np.int16, slot_samples=sum(lens) + 1, slot_utts=len(lens), slots=2,
+                                      copy_threads=2, direct=direct) as feed:
+                            fed = list(feed.run([pcm, pcm[::-1]], preemphasis=coeff))
+                        kinds["feed"] = kinds.get("feed", 0) + 1
+                        same = all(np.array_equal(fed[0][b], y16[rows16[b] : rows16[b + 1]]) for b in range(len(lens)))
+                        same &= all(np.array_equal(fed[1][len(lens) - 1 - b], y16[rows16[b] : rows16[b + 1]]) for b in range(len(lens)))
+                        if not same:
+                            fails += 1
+                            print("FAIL feed", "direct" if direct else "staged", json.dumps(cfg))
                 x = torch.from_numpy(sigs[6]).cuda()
                 y, _ = comp.compute_packed(x, [0], [lens[6]], generic=True)
                 ok, msg = close(y.cpu().numpy(), want[6], is_log=bool(comp._log), **tol)
