@@ -1,7 +1,7 @@
 // Fused STFT filter-bank path, host side: the plan's tables for the kernel of stft_wave_kernel.h
 // (fast_tables_create), the dispatch over the instantiated geometries (stft_geoms.def, one object file each:
 // stft_geom.hip) and the small helper kernels.
-#include "stft_wave_kernel.h"
+#include "stft_wave_launch.h"
 
 namespace pds {
 

@@ -1,7 +1,7 @@
 // One instantiated geometry of the fused STFT kernel (stft_wave_kernel.h) per object file: compiled with
 // -DPDS_G_N1=.. -DPDS_G_N2=.. -DPDS_G_ROWS=.. -DPDS_G_MINW=.. for every PDS_GEOM line of stft_geoms.def (Makefile),
 // so that the ~250 kernel instantiations of the library build in parallel.
-#include "stft_wave_kernel.h"
+#include "stft_wave_launch.h"
 
 #define PDS_GEOM_NAME_(a, b, c) launch_geom_##a##_##b##_##c
 #define PDS_GEOM_NAME(a, b, c) PDS_GEOM_NAME_(a, b, c)
