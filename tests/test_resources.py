@@ -41,6 +41,8 @@ DEFAULT_PATH = [
     _key(32, 16, 25, 16, 4, tin="d"),                         # ... float64 samples
     _key(32, 16, 25, 16, 4, tin="d", tout="d"),
     _key(32, 16, 25, 16, 4, pre="T", tin="d"),                # the reference drivers' flow: float64 audio, pre-emphasis
+    _key(32, 16, 25, 16, 4, tin="s"),                         # ... int16 PCM
+    _key(32, 16, 25, 16, 4, pre="T", tin="s"),
     _key(32, 16, 25, 12, 3, dlt=2),                           # configs[2]: statics + deltas in one launch
     _key(32, 16, 25, 12, 3, dlt=2, pre="T"),
     _key(32, 16, 25, 12, 3, dlt=2, tin="d"),
@@ -50,6 +52,7 @@ DEFAULT_PATH = [
     _key(64, 16, 60, 12, 3),                                  # 20 ms frames at 48 kHz, mel bank
     _key(64, 16, 60, 8, 2, tin="d"),
     _key(64, 16, 60, 8, 2, pre="T", tin="d"),
+    _key(64, 16, 60, 12, 3, tin="s"),
     _key(64, 32, 38, 12, 3, rsg="F"),                         # 25 ms frames at 48 kHz (N = 2048, lean form)
 ]
 
@@ -65,10 +68,13 @@ def test_default_path_kernels_have_no_scratch():
 
 def test_instantiation_matrix_stays_bounded():
     """ product build: fewer than 260 instantiations of the fused kernel, device code below
-    3.5 MB, and no kernel anywhere in the library with more than 40 spilled registers"""
+    3.9 MB (3.4 MB without the 34 int16-sample instantiations that came after that item), and no kernel anywhere in
+    the library with more than 40 spilled registers"""
     table, text = _table()
     stft = [k for k in table if k.startswith("stft_wave<")]
     assert 0 < len(stft) < 260, len(stft)
-    assert text < 3.5e6, text
+    assert text < 3.9e6, text
+    int16 = [k for k in stft if "TIN=s" in k]
+    assert 0 < len(int16) <= 34, len(int16)
     worst = max(table.values(), key=lambda k: k.get("vgpr_spill_count", 0))
     assert worst.get("vgpr_spill_count", 0) <= 40, worst
