@@ -95,6 +95,11 @@ extern unsigned long long *g_stamp_buf;  // (stft_fast.hip: pds_debug_set_stamp_
 #ifndef PDS_EXPERIMENTS
 #define PDS_EXPERIMENTS 0
 #endif
+// fused pre-emphasis of the 16-lane geometries: 1 = the predecessor sample as a DPP operand of the multiply-add
+// (two per row), 0 = mov_dpp + select + multiply-add (three per row; rounds 1-3a)
+#ifndef PDS_PREEMPH_DPP
+#define PDS_PREEMPH_DPP 1
+#endif
 #ifndef PDS_DYN
 #define PDS_DYN 0
 #endif
