@@ -190,6 +190,79 @@ PDS_HD void rdft_scaled(const float *a, float &even_sum, float &odd_sum, float *
   });
 }
 
+// DFT of M real points by decimation in time ON REAL DATA (no detour over a complex transform of half the size and
+// its untangling): the transform of the even samples E and of the odd samples O -- both of real sequences, so both
+// half spectra -- are combined as A[k] = E[k] + W_M^k O[k], A[M/2 - k] = conj(E[k] - W_M^k O[k]) for k = 1 ..
+// M/4 - 1 (six multiply-adds per pair), A[M/4] = E[M/4] - i O[M/4] (both real: free), A[0] / A[M/2] = E[0] +- O[0].
+// 6 (M/4 - 1) + 2 instructions per level: 162 for M = 32 against the 230 of rdft_scaled (a 16-point complex
+// transform and 70 instructions of untangling), 418 against 580 for M = 64; literal-zero inputs (the padded tail of
+// the frame) prune both alike.  Outputs UNSCALED: (Ar, Ai)[k] = A[k], k = 1 .. M/2 - 1; r0 = A[0], rh = A[M/2].
+template <int M, int IS>
+struct RDIT {
+  static PDS_HD void run(const float *x, float &r0, float &rh, float *Ar, float *Ai) {
+    constexpr int H = M / 2, Q = M / 4;
+    float e0, eh, o0, oh;
+    float Er[Q > 1 ? Q : 1], Ei[Q > 1 ? Q : 1], Or[Q > 1 ? Q : 1], Oi[Q > 1 ? Q : 1];
+    RDIT<H, 2 * IS>::run(x, e0, eh, Er, Ei);
+    RDIT<H, 2 * IS>::run(x + IS, o0, oh, Or, Oi);
+    r0 = e0 + o0;
+    rh = e0 - o0;
+    Ar[Q] = eh;
+    Ai[Q] = -oh;
+    static_for<1, Q>([&](auto kk) {
+      constexpr int k = decltype(kk)::value;
+      constexpr float c = Tw<M, k>::re, s = Tw<M, k>::im;
+      // E + W O as chained multiply-adds per component, the mirrored output conj(E - W O) = conj(2 E - (E + W O))
+      const float ar = fmaf(Or[k], c, fmaf(-s, Oi[k], Er[k]));
+      const float ai = fmaf(Or[k], s, fmaf(c, Oi[k], Ei[k]));
+      Ar[k] = ar;
+      Ai[k] = ai;
+      Ar[H - k] = fmaf(2.0f, Er[k], -ar);
+      Ai[H - k] = fmaf(-2.0f, Ei[k], ai);
+    });
+  }
+};
+template <int IS>
+struct RDIT<2, IS> {
+  static PDS_HD void run(const float *x, float &r0, float &rh, float *, float *) {
+    r0 = x[0] + x[IS];
+    rh = x[0] - x[IS];
+  }
+};
+template <int IS>
+struct RDIT<4, IS> {
+  static PDS_HD void run(const float *x, float &r0, float &rh, float *Ar, float *Ai) {
+    const float e0 = x[0] + x[2 * IS], e1 = x[0] - x[2 * IS];
+    const float o0 = x[IS] + x[3 * IS], o1 = x[IS] - x[3 * IS];
+    r0 = e0 + o0;
+    rh = e0 - o0;
+    Ar[1] = e1;
+    Ai[1] = -o1;
+  }
+};
+// ... with the interface of rdft_scaled (even_sum / odd_sum instead of A[0] / A[M/2]) and UNSCALED outputs
+template <int M>
+PDS_HD void rdft_dit(const float *a, float &even_sum, float &odd_sum, float *Ar, float *Ai) {
+  static_assert(M >= 8 && (M & (M - 1)) == 0, "power-of-two in-lane transform");
+  constexpr int H = M / 2, Q = M / 4;
+  float eh, oh;
+  float Er[Q], Ei[Q], Or[Q], Oi[Q];
+  RDIT<H, 2>::run(a, even_sum, eh, Er, Ei);
+  RDIT<H, 2>::run(a + 1, odd_sum, oh, Or, Oi);
+  Ar[Q] = eh;
+  Ai[Q] = -oh;
+  static_for<1, Q>([&](auto kk) {
+    constexpr int k = decltype(kk)::value;
+    constexpr float c = Tw<M, k>::re, s = Tw<M, k>::im;
+    const float ar = fmaf(Or[k], c, fmaf(-s, Oi[k], Er[k]));
+    const float ai = fmaf(Or[k], s, fmaf(c, Oi[k], Ei[k]));
+    Ar[k] = ar;
+    Ai[k] = ai;
+    Ar[H - k] = fmaf(2.0f, Er[k], -ar);
+    Ai[H - k] = fmaf(-2.0f, Ei[k], ai);
+  });
+}
+
 // The K inter-stage twiddles W^k, k = 1..K (K = 15 or 31), of one lane (W = e^{-2 pi i r / N}, a unit complex
 // number per lane) regenerated from three seeds w1 = W, w4 = W^4, wq = W^((K + 1) / 2) instead of being held in
 // 2 K registers: K - 3 complex products (four instructions each), none more than four (K = 15) or five
@@ -202,7 +275,8 @@ PDS_HD void cmul(float ar, float ai, float br, float bi, float &cr, float &ci) {
   cr = fmaf(ar, br, -(ai * bi));
   ci = fmaf(ar, bi, ai * br);
 }
-template <int K>
+// (DOUBLE_Q = false: every twiddle of unit size, for the unscaled outputs of rdft_dit and a whole window)
+template <int K, bool DOUBLE_Q = true>
 PDS_HD void twiddle_chain(float w1r, float w1i, float w4r, float w4i, float wqr, float wqi, float *tr, float *ti) {
   static_assert(K == 15 || K == 31, "twiddles of the 32- and 64-point in-lane transforms");
   constexpr int Q = (K + 1) / 2;  // 8 or 16
@@ -224,7 +298,11 @@ PDS_HD void twiddle_chain(float w1r, float w1i, float w4r, float w4i, float wqr,
     constexpr int k = decltype(kk)::value;
     cmul(tr[k], ti[k], wqr, wqi, tr[Q + k], ti[Q + k]);
   });
-  tr[Q] = wqr + wqr, ti[Q] = wqi + wqi;
+  if constexpr (DOUBLE_Q) {
+    tr[Q] = wqr + wqr, ti[Q] = wqi + wqi;
+  } else {
+    tr[Q] = wqr, ti[Q] = wqi;
+  }
 }
 PDS_HD void twiddle_chain15(float w1r, float w1i, float w4r, float w4i, float w8r, float w8i, float *tr, float *ti) {
   twiddle_chain<15>(w1r, w1i, w4r, w4i, w8r, w8i, tr, ti);

@@ -142,7 +142,7 @@ int32_t fast_tables_create(pds_stft_plan *plan, const double *window, const int3
     for (int k1 = 1; k1 < cols; ++k1) {
       const double ang = -2.0 * M_PI * (double)((r * k1) % N) / (double)N;
       // undo rdft_scaled's factor (rdft_direct of the other sizes is unscaled)
-      const double scale = !pow2 ? 1.0 : (2 * k1 == H1) ? 1.0 : 0.5;
+      const double scale = (!pow2 || PDS_RDFT_DIT) ? 1.0 : (2 * k1 == H1) ? 1.0 : 0.5;
       tw[((size_t)r * cols + k1) * 2 + 0] = (float)(scale * std::cos(ang));
       tw[((size_t)r * cols + k1) * 2 + 1] = (float)(scale * std::sin(ang));
     }
@@ -383,7 +383,7 @@ int32_t fast_tables_create(pds_stft_plan *plan, const double *window, const int3
     // float64-sample instantiations (and the prefetch experiment): window times 1/2 and the twiddle seeds
     // W_N^r, W_N^4r, W_N^(n1/4 r) (inl::twiddle_chain)
     std::vector<float> wh(win), seed((size_t)n2 * 6);
-    for (float &v : wh) v *= 0.5f;
+    for (float &v : wh) v *= PDS_RDFT_DIT ? 1.0f : 0.5f;  // (rdft_dit: unscaled outputs, the whole window)
     const int mult[3] = {1, 4, n1 / 4};
     for (int r = 0; r < n2; ++r)
       for (int j = 0; j < 3; ++j) {

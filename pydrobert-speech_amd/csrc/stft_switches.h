@@ -97,6 +97,12 @@ extern unsigned long long *g_stamp_buf;  // (stft_fast.hip: pds_debug_set_stamp_
 #endif
 // fused pre-emphasis of the 16-lane geometries: 1 = the predecessor sample as a DPP operand of the multiply-add
 // (two per row), 0 = mov_dpp + select + multiply-add (three per row; rounds 1-3a)
+// in-lane real transform of the power-of-two geometries: 1 = decimation in time on real data (inl::rdft_dit, unscaled
+// outputs, unit twiddles), 0 = complex transform of half the size + untangling (inl::rdft_scaled; rounds 1-3a, and
+// what the matrix-pipe front end of the experiments build produces)
+#ifndef PDS_RDFT_DIT
+#define PDS_RDFT_DIT (!PDS_EXPERIMENTS)
+#endif
 #ifndef PDS_PREEMPH_DPP
 #define PDS_PREEMPH_DPP 1
 #endif

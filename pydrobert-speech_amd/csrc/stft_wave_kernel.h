@@ -1153,7 +1153,11 @@ __global__ __launch_bounds__(MAXWAVES * 64, MINW) void stft_wave_kernel(const Fa
           Ai[k] = a[2 * k + 1];
         }
       } else if constexpr (inl::is_pow2(N1)) {
+#if PDS_RDFT_DIT
+        inl::rdft_dit<N1>(a, even_sum, odd_sum, Ar, Ai);  // (unscaled outputs: unit twiddles, see fast_tables_create)
+#else
         inl::rdft_scaled<N1>(a, even_sum, odd_sum, Ar, Ai);
+#endif
       } else {
         inl::rdft_direct<N1>(a, even_sum, odd_sum, Ar, Ai);
       }
@@ -1181,7 +1185,7 @@ __global__ __launch_bounds__(MAXWAVES * 64, MINW) void stft_wave_kernel(const Fa
         // would sit in the thirty registers it is there to free)
 #pragma unroll
         for (int j = 0; j < 6; ++j) asm volatile("" : "+v"(sd[j]));
-        inl::twiddle_chain<NREG>(sd[0], sd[1], sd[2], sd[3], sd[4], sd[5], ctr, cti);
+        inl::twiddle_chain<NREG, !PDS_RDFT_DIT>(sd[0], sd[1], sd[2], sd[3], sd[4], sd[5], ctr, cti);
       }
 #pragma unroll
       for (int k1 = 1; k1 <= NREG; ++k1) {
@@ -1402,9 +1406,9 @@ __global__ __launch_bounds__(MAXWAVES * 64, MINW) void stft_wave_kernel(const Fa
         const float ti = sw.y * di - sw.x * dr;
         const float xr = sr + tr, xi = si + ti;  // 2 X[m]
         const float yr = sr - tr, yi = ti - si;  // 2 X[N2 - m]
-        // (TWCHAIN: the window carries the factor 1/2 already)
-        sp0 = (TWCHAIN ? 1.0f : 0.25f) * (xr * xr + xi * xi);
-        sp1 = (TWCHAIN ? 1.0f : 0.25f) * (yr * yr + yi * yi);
+        // (TWCHAIN with rdft_scaled: the window carries the factor 1/2 already)
+        sp0 = (TWCHAIN && !PDS_RDFT_DIT ? 1.0f : 0.25f) * (xr * xr + xi * xi);
+        sp1 = (TWCHAIN && !PDS_RDFT_DIT ? 1.0f : 0.25f) * (yr * yr + yi * yi);
       }
     }
     if (!use_power) {

@@ -63,6 +63,28 @@ static void check_rdft() {
   g_worst = fmax(g_worst, fmax(worst, worst_p) / sqrt((double)M));
 }
 
+// real decimation in time: unscaled outputs, same interface
+template <int M>
+static void check_rdft_dit() {
+  constexpr int H = M / 2;
+  float a[M], Ar[H + 1] = {0}, Ai[H + 1] = {0}, ev, od;
+  for (int i = 0; i < M; ++i) a[i] = (float)frand();
+  rdft_dit<M>(a, ev, od, Ar, Ai);
+  double worst = 0, evs = 0, ods = 0;
+  for (int n = 0; n < M; ++n) (n % 2 ? ods : evs) += a[n];
+  worst = fmax(fabs(evs - ev), fabs(ods - od));
+  for (int k = 1; k < H; ++k) {
+    double re = 0, im = 0;
+    for (int n = 0; n < M; ++n) {
+      re += a[n] * cos(2.0 * M_PI * n * k / M);
+      im -= a[n] * sin(2.0 * M_PI * n * k / M);
+    }
+    worst = fmax(worst, fmax(fabs(re - Ar[k]), fabs(im - Ai[k])));
+  }
+  printf("rdft_dit<%d> max abs err %.3g\n", M, worst);
+  g_worst = fmax(g_worst, worst / sqrt((double)M));
+}
+
 // sizes that are not powers of two: unscaled outputs k = 1 .. (M - 1) / 2, and the column sums
 template <int M>
 static void check_rdft_direct() {
@@ -95,6 +117,7 @@ int main() {
   check_cfft<1>(); check_cfft<2>(); check_cfft<4>(); check_cfft<8>(); check_cfft<16>();
   check_cfft<32>(); check_cfft<64>(); check_cfft<128>();
   check_rdft<4>(); check_rdft<8>(); check_rdft<16>(); check_rdft<32>(); check_rdft<64>(); check_rdft<128>();
+  check_rdft_dit<8>(); check_rdft_dit<16>(); check_rdft_dit<32>(); check_rdft_dit<64>(); check_rdft_dit<128>();
   check_rdft_direct<10>(); check_rdft_direct<15>(); check_rdft_direct<20>(); check_rdft_direct<25>();
   check_rdft_direct<30>(); check_rdft_direct<12>(); check_rdft_direct<50>();
   printf("worst normalised error %.3g\n", g_worst);
