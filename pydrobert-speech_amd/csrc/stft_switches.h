@@ -103,6 +103,13 @@ extern unsigned long long *g_stamp_buf;  // (stft_fast.hip: pds_debug_set_stamp_
 #ifndef PDS_RDFT_DIT
 #define PDS_RDFT_DIT (!PDS_EXPERIMENTS)
 #endif
+// 1: window multiplies of the rows that lie wholly inside a frame as ordinary multiplies, which the compiler contracts
+// with the transform's first additions (9 vector instructions fewer per item at N = 512 -- and the same time, +-0.7 %,
+// profiles/r3r_window_contract_ab.txt: a three-register v_fma_f32 costs 1.3 nJ where the multiply and the add it replaces cost 0.9
+// each, profiles/r3p_energy_microbench.txt); 0 (product): v_mul_legacy_f32 for every row
+#ifndef PDS_WINDOW_CONTRACT
+#define PDS_WINDOW_CONTRACT 0
+#endif
 #ifndef PDS_PREEMPH_DPP
 #define PDS_PREEMPH_DPP 1
 #endif

@@ -107,6 +107,20 @@ __device__ __forceinline__ float mul_legacy(float x, float y) {
   return z;
 }
 
+// The window multiply of row n1 of a frame.  Rows below N1 / 2 lie wholly inside the frame (the kernel requires
+// L > N / 2); a row above may hold lanes past the frame's end -- they read samples of the next frame, possibly Inf / NaN,
+// and their window value is exactly 0 -- and takes the 0 * x = 0 multiply.  The ordinary multiplies of the rows below
+// contract with the transform's first additions, x[n] +- x[n + N1/2]: one multiply and two multiply-adds per pair
+// instead of two and two.
+template <int N1>
+__device__ __forceinline__ float window_mul(int n1, float x, float w) {
+#if PDS_WINDOW_CONTRACT
+  return n1 < N1 / 2 ? x * w : mul_legacy(x, w);
+#else
+  return mul_legacy(x, w);
+#endif
+}
+
 // DPP row_shr:M of `src` into `old`: lane i of a 16-lane row takes src of lane i - M; lanes whose
 // source would lie outside the row keep `old`
 template <int M>
@@ -1125,7 +1139,7 @@ __global__ __launch_bounds__(MAXWAVES * 64, MINW) void stft_wave_kernel(const Fa
       PDS_PHASE(4);
       if constexpr (WINLDS) {
 #pragma unroll
-        for (int n1 = 0; n1 < NROWS; ++n1) a[n1] = mul_legacy(a[n1], wl[n1]);
+        for (int n1 = 0; n1 < NROWS; ++n1) a[n1] = window_mul<N1>(n1, a[n1], wl[n1]);
       } else if constexpr (WINUSE) {
         const float4 *w4 = reinterpret_cast<const float4 *>(win_lds + rho * WSTR);
 #pragma unroll
@@ -1134,11 +1148,11 @@ __global__ __launch_bounds__(MAXWAVES * 64, MINW) void stft_wave_kernel(const Fa
           const float wv[4] = {w.x, w.y, w.z, w.w};
 #pragma unroll
           for (int u = 0; u < 4; ++u)
-            if (4 * j + u < NROWS) a[4 * j + u] = mul_legacy(a[4 * j + u], wv[u]);
+            if (4 * j + u < NROWS) a[4 * j + u] = window_mul<N1>(4 * j + u, a[4 * j + u], wv[u]);
         }
       } else {
 #pragma unroll
-        for (int n1 = 0; n1 < NROWS; ++n1) a[n1] = mul_legacy(a[n1], win[n1]);
+        for (int n1 = 0; n1 < NROWS; ++n1) a[n1] = window_mul<N1>(n1, a[n1], win[n1]);
       }
       if constexpr (PF) fetch_next_record();
 #pragma unroll
