@@ -110,6 +110,11 @@ extern unsigned long long *g_stamp_buf;  // (stft_fast.hip: pds_debug_set_stamp_
 #ifndef PDS_WINDOW_CONTRACT
 #define PDS_WINDOW_CONTRACT 0
 #endif
+// packed real column of the 16-lane geometries handed from lane 0 to the lanes that untangle it: 0 = 32 DPP moves,
+// 1 = through the wave's LDS area (eight 16-byte writes of lane 0, two 8-byte reads per lane)
+#ifndef PDS_PACKED_LDS
+#define PDS_PACKED_LDS 0
+#endif
 #ifndef PDS_PREEMPH_DPP
 #define PDS_PREEMPH_DPP 1
 #endif

@@ -1390,7 +1390,7 @@ __global__ __launch_bounds__(MAXWAVES * 64, MINW) void stft_wave_kernel(const Fa
         // pair each -- a few moves + 20 flops for every lane instead of a block of ~10 N2
         // instructions that only lane 0 needs.
         float ar, ai, br, bi;
-        if constexpr (N2 == 16) {
+        if constexpr (N2 == 16 && !PDS_PACKED_LDS) {
           // a lane group is one DPP row, so "row_shr:m, keep old where the source lane is outside
           // the row", applied for m = 1, 2, ... in order, leaves lane m with lane 0's register m
           ar = Yr[0], ai = Yi[0], br = Yr[0], bi = Yi[0];
@@ -1407,8 +1407,14 @@ __global__ __launch_bounds__(MAXWAVES * 64, MINW) void stft_wave_kernel(const Fa
           // (LEAN: the frame's block is addressed in floats; its first 2 N2 of them take the column)
           float2 *hand = G::LEAN ? reinterpret_cast<float2 *>(xf) : exch;
           if (r == 0) {
+            if constexpr (N2 % 2 == 0) {
+              float4 *hand4 = reinterpret_cast<float4 *>(hand);
 #pragma unroll
-            for (int k2 = 0; k2 < N2; ++k2) hand[k2] = make_float2(Yr[k2], Yi[k2]);
+              for (int k2 = 0; k2 < N2; k2 += 2) hand4[k2 / 2] = make_float4(Yr[k2], Yi[k2], Yr[k2 + 1], Yi[k2 + 1]);
+            } else {
+#pragma unroll
+              for (int k2 = 0; k2 < N2; ++k2) hand[k2] = make_float2(Yr[k2], Yi[k2]);
+            }
           }
           wave_sync();
           const float2 ya = hand[r], yb = hand[(N2 - r) & (N2 - 1)];
