@@ -722,6 +722,13 @@ class ShortTimeFourierTransformFrameComputer(LinearFilterBankFrameComputer):
         in_dtype = signal.dtype
         if nframes <= 0:
             return np.empty((0, self.num_coeffs), dtype=in_dtype)
+        if pad_left is None and nframes == self.num_frames(len(signal)):
+            # compute_full of one host signal: through a small staging ring in direct mode -- the kernel reads the
+            # pinned copy of the signal and writes the pinned features itself, no upload / download calls: 145 -> 80 us
+            # per call for 10 s of audio (tools/latency.py)
+            fed = self._one_signal_through_feed(signal, in_dtype)
+            if fed is not None:
+                return fed
         work = np.array(signal, dtype=self._compute_dtype(in_dtype), copy=True, order="C")
         d_sig = torch.from_numpy(work).to("cuda")
         feats, _ = self.compute_packed(d_sig, [0], [len(work)], [nframes], pad_left)
@@ -745,6 +752,29 @@ class ShortTimeFourierTransformFrameComputer(LinearFilterBankFrameComputer):
         if signal.ndim != 1:
             raise ValueError("signal must be 1-dimensional")
         return self._run_host_signal(signal, self.num_frames(len(signal)), None)
+
+    def _one_signal_through_feed(self, signal, in_dtype):
+        from .feed import HostFeed  # (imports this module)
+
+        torch = _native.require_device()
+        f64 = in_dtype == np.float64 and config.FLOAT64_ARITHMETIC == "float32"
+        n = len(signal)
+        if not config.HOST_FEED or not (in_dtype == np.float32 or f64) or n > _FEED_SLOT_SAMPLES:
+            return None
+        plan = self._native_plan()
+        if not plan.kernel_kind or (f64 and not plan.has_f64in):
+            return None
+        key = (torch.cuda.current_device(), np.dtype(in_dtype), "one")
+        feed = self._feeds.get(key)
+        if feed is None or feed.slot_samples < n:
+            if feed is not None:
+                feed.close()
+            size = 1 << 20
+            while size < n:
+                size <<= 1
+            feed = self._feeds[key] = HostFeed(self, in_dtype, slot_samples=size, slot_utts=1, slots=1, copy_threads=2)
+        feats, _ = feed.collect(feed.submit([signal]))
+        return feats if feats.dtype == in_dtype else feats.astype(in_dtype)
 
     def _full_batch_through_feed(self, signals, lengths, in_dtype, preemphasis):
         """Host signals through the pinned staging ring (``feed.HostFeed``): slot-sized pieces of the batch upload,

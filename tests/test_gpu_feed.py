@@ -155,3 +155,20 @@ def test_compute_full_batch_of_host_signals_goes_through_the_feed(golden_meta, m
     for g, w in zip(got, want):
         assert g.dtype == w.dtype == np.float32
         np.testing.assert_array_equal(g, w)
+
+
+def test_compute_full_of_one_host_signal_goes_through_a_small_direct_feed(golden_meta, monkeypatch):
+    """compute_full(numpy signal): the kernel reads the pinned copy of the signal and writes the pinned features
+    itself (no upload / download calls) -- the plain path's values bit for bit, for signals that outgrow the slot too"""
+    from pydrobert_speech_amd import config
+
+    comp = build(golden_meta["configs"]["c1_kaldi_fbank"])
+    rng = np.random.default_rng(15)
+    sigs = [(3000 * rng.standard_normal(n)).astype(np.float32) for n in (16000, 1, 0, 400, 1 << 21, 77777)]
+    got = [comp.compute_full(x) for x in sigs]
+    assert any(len(k) == 3 for k in comp._feeds), "compute_full did not go through the feed"
+    monkeypatch.setattr(config, "HOST_FEED", False)
+    for x, g in zip(sigs, got):
+        w = comp.compute_full(x)
+        assert g.dtype == w.dtype == np.float32 and g.shape == w.shape
+        np.testing.assert_array_equal(g, w)
