@@ -49,20 +49,24 @@ enum Kind {
   K_MFMA_F16,   // v_mfma_f32_16x16x32_f16
   K_CVT,        // v_cvt_pkrtz_f16_f32
   K_LOG,        // v_log_f32
+  K_GLOAD_L2,   // global_load_dword, 256 B per wave-instruction, a 2 MB window per workgroup's XCD (L2 hits)
+  K_GLOAD_HBM,  // ... streaming through 2 GB (HBM)
+  K_GSTORE,     // global_store_dword, streaming through 1 GB
   K_COUNT
 };
 static const char *kind_name[K_COUNT] = {"idle(s_sleep)", "s_nop", "v_fma_f32", "v_fma_f32 zeros", "v_fmac_f32", "v_fmamk_f32",
                                          "v_add_f32", "v_mul_f32", "v_pk_fma_f32", "v_pk_add_f32", "v_pk_mul_f32", "v_mov_b32",
                                          "v_mov_b32 dpp", "ds_read_b128", "ds_write_b64", "mfma_f32_16x16x4_f32", "mfma_f32_4x4x1_f32",
-                                         "mfma_f32_16x16x32_f16", "v_cvt_pkrtz_f16_f32", "v_log_f32"};
+                                         "mfma_f32_16x16x32_f16", "v_cvt_pkrtz_f16_f32", "v_log_f32", "global_load_dword (L2)",
+                                         "global_load_dword (HBM)", "global_store_dword (HBM)"};
 // wave-instructions of the measured kind per loop iteration
-static const int kind_per_iter[K_COUNT] = {1, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 16, 16, 16, 16, 16, 64, 64};
+static const int kind_per_iter[K_COUNT] = {1, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 16, 16, 16, 16, 16, 64, 64, 16, 16, 16};
 
 #define R4(x) x x x x
 #define R16(x) R4(R4(x))
 
 template <int KIND>
-__global__ __launch_bounds__(256, 4) void bench(const float *in, float *out, int iters) {
+__global__ __launch_bounds__(256, 4) void bench(const float *in, float *out, int iters, float *big = nullptr) {
   const int t = threadIdx.x + blockIdx.x * blockDim.x;
   float a[16];
 #pragma unroll
@@ -201,6 +205,24 @@ __global__ __launch_bounds__(256, 4) void bench(const float *in, float *out, int
       }
 #pragma unroll
       for (int i = 0; i < 16; ++i) a[i] += 1e-30f * (float)h[i];
+    } else if constexpr (KIND == K_GLOAD_L2 || KIND == K_GLOAD_HBM) {
+      // 16 loads of 256 contiguous bytes per wave in flight, then one wait (as the kernel's 25 per item)
+      const size_t window = KIND == K_GLOAD_L2 ? (size_t)(1 << 19) : (size_t)(1 << 29);  // floats
+      const size_t wave = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+      const size_t base = KIND == K_GLOAD_L2 ? ((wave * 4099 + (size_t)it * 1024) % (window - 1024 - 64))
+                                              : ((wave * (size_t)iters + (size_t)it) * 1024 % (window - 1024 - 64));
+      const float *src = big + base + (threadIdx.x & 63);
+      float v[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) v[u] = __builtin_nontemporal_load(src + u * 64);
+#pragma unroll
+      for (int u = 0; u < 16; ++u) a[u] += v[u];
+    } else if constexpr (KIND == K_GSTORE) {
+      const size_t window = (size_t)(1 << 28);
+      const size_t wave = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+      float *dst = big + ((wave * (size_t)iters + (size_t)it) * 1024 % (window - 1024 - 64)) + (threadIdx.x & 63);
+#pragma unroll
+      for (int u = 0; u < 16; ++u) dst[u * 64] = a[u];
     } else if constexpr (KIND == K_LOG) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
@@ -252,6 +274,8 @@ static std::vector<Hwmon> find_hwmons() {
   return r;
 }
 
+static float *g_big = nullptr;
+
 template <int KIND>
 static void run(const float *d_in, float *d_out, const std::vector<Hwmon> &mons, double base_w, double *out_idle_w) {
   const int blocks = 256 * 4;  // 16 waves per CU: 4 per SIMD
@@ -260,10 +284,10 @@ static void run(const float *d_in, float *d_out, const std::vector<Hwmon> &mons,
   hipEvent_t e0, e1;
   CHECK(hipEventCreate(&e0));
   CHECK(hipEventCreate(&e1));
-  hipLaunchKernelGGL(bench<KIND>, dim3(blocks), dim3(256), 0, 0, d_in, d_out, 100);
+  hipLaunchKernelGGL(bench<KIND>, dim3(blocks), dim3(256), 0, 0, d_in, d_out, 100, g_big);
   CHECK(hipDeviceSynchronize());
   CHECK(hipEventRecord(e0));
-  hipLaunchKernelGGL(bench<KIND>, dim3(blocks), dim3(256), 0, 0, d_in, d_out, iters);
+  hipLaunchKernelGGL(bench<KIND>, dim3(blocks), dim3(256), 0, 0, d_in, d_out, iters, g_big);
   CHECK(hipEventRecord(e1));
   CHECK(hipEventSynchronize(e1));
   float ms;
@@ -290,7 +314,7 @@ static void run(const float *d_in, float *d_out, const std::vector<Hwmon> &mons,
   double kernel_ms = 0.0;
   while (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() < 2.5) {
     CHECK(hipEventRecord(e0));
-    for (int i = 0; i < 20; ++i) hipLaunchKernelGGL(bench<KIND>, dim3(blocks), dim3(256), 0, 0, d_in, d_out, iters);
+    for (int i = 0; i < 20; ++i) hipLaunchKernelGGL(bench<KIND>, dim3(blocks), dim3(256), 0, 0, d_in, d_out, iters, g_big);
     CHECK(hipEventRecord(e1));
     CHECK(hipEventSynchronize(e1));
     CHECK(hipEventElapsedTime(&ms, e0, e1));
@@ -334,6 +358,8 @@ int main() {
   CHECK(hipMalloc(&d_in, h.size() * 4));
   CHECK(hipMalloc(&d_out, 256 * 4 * 256 * 4));
   CHECK(hipMemcpy(d_in, h.data(), h.size() * 4, hipMemcpyHostToDevice));
+  CHECK(hipMalloc(&g_big, (size_t)(1 << 29) * sizeof(float)));
+  CHECK(hipMemset(g_big, 0, (size_t)(1 << 29) * sizeof(float)));
   double idle_w = 0.0;
   run<K_IDLE>(d_in, d_out, mons, 0.0, &idle_w);
   printf("resident-idle baseline: %.1f W\n", idle_w);
@@ -356,5 +382,8 @@ int main() {
   run<K_MFMA_F16>(d_in, d_out, mons, idle_w, nullptr);
   run<K_CVT>(d_in, d_out, mons, idle_w, nullptr);
   run<K_LOG>(d_in, d_out, mons, idle_w, nullptr);
+  run<K_GLOAD_L2>(d_in, d_out, mons, idle_w, nullptr);
+  run<K_GLOAD_HBM>(d_in, d_out, mons, idle_w, nullptr);
+  run<K_GSTORE>(d_in, d_out, mons, idle_w, nullptr);
   return 0;
 }
