@@ -672,8 +672,11 @@ def main():
                 "algorithmic_bytes_per_frame": bytes_per_frame,
                 "frames_per_s_per_gpu_kernel_only": frames / k_avg_s,
                 "secondary": secondary,
-                # the limit this kernel actually runs into on MI355X: the socket's power cap
-                "power": power,
+                # the limit this kernel actually runs into on MI355X: the socket's power cap --
+                # at the cap a step's joules ARE its time (modelled per instruction kind: profiles/r3s_energy_microbench.txt)
+                "power": ({**power, "joules_per_step": power["socket_w"] * 1e-3 * power["ms_per_step_during_probe"],
+                           "nj_per_frame": power["socket_w"] * 1e-3 * power["ms_per_step_during_probe"] / frames * 1e9}
+                          if power and "socket_w" in power else power),
             },
             "cold_ms_per_step": cold_ms,
             "outputs_finite": finite,
