@@ -180,8 +180,9 @@ int32_t pds_stft_batch_ragged_f32(const pds_stft_plan *plan, const float *d_sign
  * another walk for the plain launch sums the same products in another order: a few float32 ulps.) */
 int32_t pds_stft_plan_has_fused_deltas(const pds_stft_plan *plan);
 /* ... with everything the reference's drivers put in front of compute_full (command_line.py:345-350): `d_signal`
- * float32 (signal_is_f64 = 0) or float64 samples (1: plans with pds_stft_plan_has_f64in(); rounded to float32 as the
- * frame is loaded, as in pds_stft_batch_f64in) and a fused pre-emphasis (`preemph` != 0, pre.py:140-149: in the
+ * float32 (signal_is_f64 = 0 = PDS_SAMPLES_F32), float64 (1: plans with pds_stft_plan_has_f64in(); rounded to float32
+ * as the frame is loaded, as in pds_stft_batch_f64in) or int16 samples (2 = PDS_SAMPLES_I16: same plans; converted as
+ * the frame is loaded, as in pds_stft_batch_i16in) and a fused pre-emphasis (`preemph` != 0, pre.py:140-149: in the
  * signal's own precision, before the rounding).  float64 audio -> Preemphasize -> compute_full -> Deltas in one
  * launch; features float32.  workspace_prepared != 0: d_workspace already holds the batch's chunk prefix sums
  * (pds_stft_prepare_chunk_prefix(), see pds_stft_cmvn_batch_f32) and no kernel runs in front. */

@@ -566,7 +566,8 @@ class ShortTimeFourierTransformFrameComputer(LinearFilterBankFrameComputer):
         ``config.FLOAT64_ARITHMETIC == "float32"`` (samples rounded as the frame is loaded, after the
         pre-emphasis: ``pds_stft_deltas_batch``) -- the reference drivers' chain float64 audio ->
         Preemphasize -> compute_full -> Deltas (command_line.py:345-350) as one kernel.  Otherwise their
-        statics are computed in float64 (:func:`launch`) and rounded into the float32 result.
+        statics are computed in float64 (:func:`launch`) and rounded into the float32 result.  int16 signals
+        (16-bit PCM) take the one launch too.
         """
         if fused is None:
             fused = True
@@ -582,10 +583,11 @@ class ShortTimeFourierTransformFrameComputer(LinearFilterBankFrameComputer):
         plan = self._native_plan(signal.device)
         filts = deltas._filts[1:]
         f64in = signal.dtype == torch.float64 and config.FLOAT64_ARITHMETIC == "float32" and plan.has_f64in
-        if signal.dtype not in (torch.float32, torch.float64):
-            raise TypeError("signal must be float32 or float64")
+        i16in = signal.dtype == torch.int16 and plan.has_i16in
+        if signal.dtype not in (torch.float32, torch.float64, torch.int16):
+            raise TypeError("signal must be float32, float64 or int16")
         fused = (
-            fused and plan.has_fused_deltas and (signal.dtype == torch.float32 or f64in) and K in (1, 2) and deltas.concatenate
+            fused and plan.has_fused_deltas and (signal.dtype == torch.float32 or f64in or i16in) and K in (1, 2) and deltas.concatenate
             and deltas._pad_mode == "edge" and not deltas._pad_kwargs
             and [len(f) for f in filts] == [5, 9][:K] and total > 0
         )
@@ -606,7 +608,7 @@ class ShortTimeFourierTransformFrameComputer(LinearFilterBankFrameComputer):
                 for lo in range(0, layout.B, _MAX_UTTS_PER_CALL):
                     hi = min(layout.B, lo + _MAX_UTTS_PER_CALL)
                     rc = lib.pds_stft_deltas_batch(
-                        plan.handle, signal.data_ptr(), int(signal.dtype == torch.float64), meta[0, lo:].data_ptr(),
+                        plan.handle, signal.data_ptr(), {torch.float64: 1, torch.int16: 2}.get(signal.dtype, 0), meta[0, lo:].data_ptr(),
                         meta[1, lo:].data_ptr(), meta[2, lo:].data_ptr(), meta[3, lo:].data_ptr(), hi - lo,
                         int(layout.nframes[lo:hi].max()), pad, float(preemphasis), K, 2, taps.ctypes.data,
                         work.data_ptr(), int(single), out.data_ptr(), out.stride(0), stream,
@@ -616,7 +618,7 @@ class ShortTimeFourierTransformFrameComputer(LinearFilterBankFrameComputer):
                         break
                     _native.check(rc, "pds_stft_deltas_batch")
         if not fused:
-            if signal.dtype == torch.float32 or f64in:
+            if signal.dtype in (torch.float32, torch.int16) or f64in:
                 self.launch(signal, layout, out=out, pad_left=pad_left, preemphasis=preemphasis)
             elif total:
                 # float64 arithmetic (config.FLOAT64_ARITHMETIC == "float64"): float64 statics, rounded into the rows

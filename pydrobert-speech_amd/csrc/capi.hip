@@ -255,8 +255,9 @@ int32_t pds_stft_deltas_batch(const pds_stft_plan *plan, const void *d_signal, i
   if (rc == 1) return PDS_OK;
   if (rc != PDS_OK) return rc;
   if (!pds::fast_has_fused_deltas(plan)) return invalid("stft_deltas_batch: the plan has no fused statics + deltas kernel");
+  if (signal_is_f64 < 0 || signal_is_f64 > 2) return invalid("stft_deltas_batch: sample format must be 0 (float32), 1 (float64) or 2 (int16)");
   if (signal_is_f64 && !pds::fast_has_f64in(plan))
-    return invalid("stft_deltas_batch: float64 samples are not served for this plan (pds_stft_plan_has_f64in)");
+    return invalid("stft_deltas_batch: float64 / int16 samples are not served for this plan (pds_stft_plan_has_f64in)");
   if (num_deltas < 1 || num_deltas > 2 || context_window != 2 || !taps)
     return invalid("stft_deltas_batch: orders 1 and 2 with context_window 2 only (and their taps)");
   if (!d_workspace) return invalid("stft_deltas_batch: null workspace (B + 1 int64 on the device)");
@@ -266,7 +267,8 @@ int32_t pds_stft_deltas_batch(const pds_stft_plan *plan, const void *d_signal, i
   if (rc != PDS_OK) return rc;
   pds::BatchArgs a{d_signal,   d_offsets, d_lengths,  d_nframes, d_row_off, B, max_frames,
                    pad_left < 0 ? plan->d.pad_left : pad_left, preemph, d_out, out_stride, (hipStream_t)stream};
-  a.in_f64 = signal_is_f64 != 0;
+  a.in_f64 = signal_is_f64 == 1;
+  a.in_i16 = signal_is_f64 == 2;
   a.dl_K = num_deltas;
   a.d_chunk_prefix = d_workspace;
   a.prefix_prepared = workspace_prepared != 0;

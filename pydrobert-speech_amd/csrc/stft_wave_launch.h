@@ -312,11 +312,11 @@ int32_t launch_wave(const pds_stft_plan *plan, const BatchArgs &a) {
   // HBM): converted as the frame is loaded, then exactly the float32 kernel; the geometries of the float64-sample
   // path, ELL or row-segment walk, LDS-resident tables
   int i16_which = -1;
-  if (a.in_i16) {
+  if (a.in_i16 && a.dl_K == 0) {
     constexpr bool I16IN = fast_f64in_kind(N1 * N2);
     if constexpr (I16IN) {
-      if (a.in_f64 || a.out_f64 || a.dl_K > 0 || a.d_stat_part) {
-        set_error("stft_batch_i16in: float32 features, no fused deltas / CMVN sums");
+      if (a.in_f64 || a.out_f64 || a.d_stat_part) {
+        set_error("stft_batch_i16in: float32 features, no fused CMVN sums");
         return PDS_ERR_INVALID;
       }
       mf = false;
@@ -345,8 +345,11 @@ int32_t launch_wave(const pds_stft_plan *plan, const BatchArgs &a) {
       }
       mf = false;
       using D = double;
+      using I = int16_t;
       kern = a.in_f64 ? (pre ? stft_wave_kernel<N1, N2, NROWS, 4 * DMINW, DMINW, true, true, false, 0, true, D, float, 2>
                              : stft_wave_kernel<N1, N2, NROWS, 4 * DMINW, DMINW, true, false, false, 0, true, D, float, 2>)
+             : a.in_i16 ? (pre ? stft_wave_kernel<N1, N2, NROWS, 4 * DMINW, DMINW, true, true, false, 0, true, I, float, 2>
+                               : stft_wave_kernel<N1, N2, NROWS, 4 * DMINW, DMINW, true, false, false, 0, true, I, float, 2>)
                       : (pre ? stft_wave_kernel<N1, N2, NROWS, 4 * DMINW, DMINW, true, true, false, 0, true, float, float, 2>
                              : stft_wave_kernel<N1, N2, NROWS, 4 * DMINW, DMINW, true, false, false, 0, true, float, float, 2>);
       if (a.in_f64 || PDS_DLT_CHAIN) {
@@ -354,7 +357,7 @@ int32_t launch_wave(const pds_stft_plan *plan, const BatchArgs &a) {
         p.tw_seed = (const float2 *)ft.d_tw_seed;
       }
       p.dl_order = a.dl_K;
-      dl_which = 18 + (a.in_f64 ? 1 : 0) + (pre ? 10 : 0);  // 18, 19, 28, 29
+      dl_which = a.in_i16 ? (pre ? 26 : 21) : 18 + (a.in_f64 ? 1 : 0) + (pre ? 10 : 0);  // 18, 19, 28, 29; int16 samples 21, 26
       for (int j = 0; j < 5; ++j) p.dl_f1[j] = (float)a.dl_taps[j];
       for (int j = 0; j < 9; ++j) p.dl_f2[j] = a.dl_K > 1 ? (float)a.dl_taps[5 + j] : 0.0f;
       p.dl_inner = plan->d.num_filts + (plan->d.include_energy ? 1 : 0);

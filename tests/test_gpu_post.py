@@ -463,7 +463,7 @@ def test_launch_with_deltas_falls_back_to_two_launches():
 
 @pytest.mark.parametrize("K", [1, 2])
 @pytest.mark.parametrize("bank", ["fbank80_energy", "mel64_1024_energy"])
-@pytest.mark.parametrize("flow", ["f32+preemph", "f64", "f64+preemph"])
+@pytest.mark.parametrize("flow", ["f32+preemph", "f64", "f64+preemph", "i16", "i16+preemph"])
 def test_fused_statics_and_deltas_launch_with_preemphasis_and_float64_samples(K, bank, flow, monkeypatch):
     """pds_stft_deltas_batch: the reference drivers' chain float64 audio -> Preemphasize -> compute_full -> Deltas
     (command_line.py:345-350) as ONE launch, against the separate launches of the same kernels' plain forms (statics
@@ -489,12 +489,13 @@ def test_fused_statics_and_deltas_launch_with_preemphasis_and_float64_samples(K,
     plan = comp._native_plan()
     assert plan.has_fused_deltas and plan.has_f64in
     coeff = 0.97 if "preemph" in flow else 0.0
-    dt = "f8" if flow.startswith("f64") else "f4"
+    dt = "f8" if flow.startswith("f64") else "i2" if flow.startswith("i16") else "f4"
     rng = np.random.default_rng(7 + K)
     S, C = comp.frame_shift, comp.num_coeffs
     deltas = Deltas(K)
     lens = [0, S, 5 * S, 9 * S + 3, 60000, 33 * S, 1, 4 * S, 12 * S, 100 * S + 7, 2 * S]
-    host = (3000 * rng.standard_normal(int(np.sum(lens)))).astype(dt)
+    host = np.clip(np.rint(3000 * rng.standard_normal(int(np.sum(lens)))), -32768, 32767).astype(dt) if dt == "i2" else (
+        3000 * rng.standard_normal(int(np.sum(lens)))).astype(dt)
     x = torch.from_numpy(host).cuda()
     offs = np.concatenate([[0], np.cumsum(lens)[:-1]])
     layout = comp.prepare_layout(offs, lens, device=x.device)

@@ -47,6 +47,8 @@ DEFAULT_PATH = [
     _key(32, 16, 25, 12, 3, dlt=2, pre="T"),
     _key(32, 16, 25, 12, 3, dlt=2, tin="d"),
     _key(32, 16, 25, 12, 3, dlt=2, pre="T", tin="d"),
+    _key(32, 16, 25, 12, 3, dlt=2, tin="s"),                  # ... 16-bit PCM -> (pre-emphasis) -> statics + deltas
+    _key(32, 16, 25, 12, 3, dlt=2, pre="T", tin="s"),
     _key(32, 16, 25, 16, 4, seg=1, rsg="F"),                  # configs[3]: Gabor-64, segmented walk
     _key(64, 16, 60, 12, 3, seg=2, rsg="F"),                  # configs[4]: gammatone-64 at 48 kHz, matrix-pipe segments, 3 waves per SIMD
     _key(64, 16, 60, 12, 3),                                  # 20 ms frames at 48 kHz, mel bank
@@ -67,14 +69,14 @@ def test_default_path_kernels_have_no_scratch():
 
 
 def test_instantiation_matrix_stays_bounded():
-    """ product build: fewer than 260 instantiations of the fused kernel, device code below
-    3.9 MB (3.4 MB without the 34 int16-sample instantiations that came after that item), and no kernel anywhere in
-    the library with more than 40 spilled registers"""
+    """ product build: fewer than 270 instantiations of the fused kernel (222 without the 46
+    int16-sample ones that came after that item), device code below 4.1 MB (3.4 MB without them), and no kernel
+    anywhere in the library with more than 40 spilled registers"""
     table, text = _table()
     stft = [k for k in table if k.startswith("stft_wave<")]
-    assert 0 < len(stft) < 260, len(stft)
-    assert text < 3.9e6, text
+    assert 0 < len(stft) < 270, len(stft)
+    assert text < 4.1e6, text
     int16 = [k for k in stft if "TIN=s" in k]
-    assert 0 < len(int16) <= 34, len(int16)
+    assert 0 < len(int16) <= 46 and len(stft) - len(int16) < 225, (len(int16), len(stft))
     worst = max(table.values(), key=lambda k: k.get("vgpr_spill_count", 0))
     assert worst.get("vgpr_spill_count", 0) <= 40, worst
