@@ -207,8 +207,15 @@ def main():
 
                     K = int(rng.integers(1, 3))
                     # (round 3: float64 samples into the same launch in half of the draws that have the kernel)
-                    as64 = bool(plan.has_f64in and rng.random() < 0.5)
-                    xs = torch.from_numpy(np.concatenate(sigs).astype("f8" if as64 else "f4")).cuda()
+                    fmt = rng.random()
+                    as64 = bool(plan.has_f64in and fmt < 0.4)
+                    as16 = bool(plan.has_i16in and fmt >= 0.7)  # (int16 PCM into the same launch)
+                    if as16:
+                        pcm16 = [np.clip(np.rint(x), -32768, 32767).astype(np.int16) for x in sigs]
+                        want = [orc.compute_full(x.astype(np.float64), p) for x in pcm16]
+                        xs = torch.from_numpy(np.concatenate(pcm16)).cuda()
+                    else:
+                        xs = torch.from_numpy(np.concatenate(sigs).astype("f8" if as64 else "f4")).cuda()
                     offs = np.concatenate([[0], np.cumsum(lens)[:-1]])
                     layout = comp.prepare_layout(offs, lens, device=xs.device)
                     C = comp.num_coeffs
@@ -220,7 +227,8 @@ def main():
                     finally:
                         ps.config.FLOAT64_ARITHMETIC = prev
                     mine = out.cpu().numpy()
-                    kinds["fused-deltas" + ("-f64in" if as64 else "")] = kinds.get("fused-deltas" + ("-f64in" if as64 else ""), 0) + 1
+                    tag = "fused-deltas" + ("-f64in" if as64 else "-i16in" if as16 else "")
+                    kinds[tag] = kinds.get(tag, 0) + 1
                     rows = layout.row_offsets
                     for b in range(len(lens)):
                         blk = mine[rows[b] : rows[b + 1]]
@@ -233,8 +241,10 @@ def main():
                             msg = f"deltas err {err.max():.3g} scale {scale:.3g}"
                         if not ok:
                             fails += 1
-                            print("FAIL fused-deltas", "len", lens[b], msg, json.dumps(cfg))
+                            print("FAIL fused-deltas", tag, "len", lens[b], msg, json.dumps(cfg))
                             break
+                    if as16:  # (the checks below compare with the float signals' features again)
+                        want = [orc.compute_full(x, p) for x in sigs]
                 # float64 samples into the fused kernel (rounded at the frame load; 16-lane geometries: pair loads)
                 if plan.has_f64in and rng.random() < 0.5:
                     xs = torch.from_numpy(np.concatenate(sigs).astype("f8")).cuda()
