@@ -287,6 +287,11 @@ int32_t pds_feed_pack(pds_feed *feed, int32_t slot, const void *const *signals, 
                       int32_t threads);
 int32_t pds_feed_submit(pds_feed *feed, int32_t slot, const int64_t *lengths, int32_t n_utts, double preemph,
                         int32_t download);
+/* ... with the frame counts and the left reflection of the call given, as pds_stft_batch_* take them (nframes NULL:
+ * pds_stft_num_frames of every length; pad_left -1: the plan's): what the streaming host logic needs, whose chunks
+ * yield the frames completed so far (compute.py:480, 552-556) */
+int32_t pds_feed_submit_frames(pds_feed *feed, int32_t slot, const int64_t *lengths, const int64_t *nframes,
+                               int32_t n_utts, int32_t pad_left, double preemph, int32_t download);
 int32_t pds_feed_device_view(pds_feed *feed, int32_t slot, void **d_features, int64_t *rows, const int64_t **row_offsets,
                              void **stream);
 int32_t pds_feed_download(pds_feed *feed, int32_t slot, const void *d_src, int64_t bytes);

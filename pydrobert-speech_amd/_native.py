@@ -163,6 +163,7 @@ SIGNATURES = {
     "pds_feed_acquire": (c_int32, [c_void_p, POINTER(c_int32), POINTER(c_void_p)]),
     "pds_feed_pack": (c_int32, [c_void_p, c_int32, c_void_p, c_void_p, c_int32, c_int32]),
     "pds_feed_submit": (c_int32, [c_void_p, c_int32, c_void_p, c_int32, c_double, c_int32]),
+    "pds_feed_submit_frames": (c_int32, [c_void_p, c_int32, c_void_p, c_void_p, c_int32, c_int32, c_double, c_int32]),
     "pds_feed_device_view": (c_int32, [c_void_p, c_int32, POINTER(c_void_p), POINTER(c_int64), POINTER(c_void_p),
                                        POINTER(c_void_p)]),
     "pds_feed_download": (c_int32, [c_void_p, c_int32, c_void_p, c_int64]),

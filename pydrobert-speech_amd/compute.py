@@ -724,13 +724,12 @@ class ShortTimeFourierTransformFrameComputer(LinearFilterBankFrameComputer):
         in_dtype = signal.dtype
         if nframes <= 0:
             return np.empty((0, self.num_coeffs), dtype=in_dtype)
-        if pad_left is None and nframes == self.num_frames(len(signal)):
-            # compute_full of one host signal: through a small staging ring in direct mode -- the kernel reads the
-            # pinned copy of the signal and writes the pinned features itself, no upload / download calls: 145 -> 80 us
-            # per call for 10 s of audio (tools/latency.py)
-            fed = self._one_signal_through_feed(signal, in_dtype)
-            if fed is not None:
-                return fed
+        # one host signal (compute_full, and every chunk of the streaming interface): through a small staging ring in
+        # direct mode -- the kernel reads the pinned copy of the signal and writes the pinned features itself, no upload /
+        # download calls: 145 -> 80 us per call for 10 s of audio (tools/latency.py)
+        fed = self._one_signal_through_feed(signal, in_dtype, nframes, pad_left)
+        if fed is not None:
+            return fed
         work = np.array(signal, dtype=self._compute_dtype(in_dtype), copy=True, order="C")
         d_sig = torch.from_numpy(work).to("cuda")
         feats, _ = self.compute_packed(d_sig, [0], [len(work)], [nframes], pad_left)
@@ -755,7 +754,7 @@ class ShortTimeFourierTransformFrameComputer(LinearFilterBankFrameComputer):
             raise ValueError("signal must be 1-dimensional")
         return self._run_host_signal(signal, self.num_frames(len(signal)), None)
 
-    def _one_signal_through_feed(self, signal, in_dtype):
+    def _one_signal_through_feed(self, signal, in_dtype, nframes, pad_left):
         from .feed import HostFeed  # (imports this module)
 
         torch = _native.require_device()
@@ -775,7 +774,9 @@ class ShortTimeFourierTransformFrameComputer(LinearFilterBankFrameComputer):
             while size < n:
                 size <<= 1
             feed = self._feeds[key] = HostFeed(self, in_dtype, slot_samples=size, slot_utts=1, slots=1, copy_threads=2)
-        feats, _ = feed.collect(feed.submit([signal]))
+        if nframes > feed.slot_rows:
+            return None
+        feats, _ = feed.collect(feed.submit([signal], nframes=[nframes], pad_left=pad_left))
         return feats if feats.dtype == in_dtype else feats.astype(in_dtype)
 
     def _full_batch_through_feed(self, signals, lengths, in_dtype, preemphasis):

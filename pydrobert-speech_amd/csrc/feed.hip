@@ -231,7 +231,13 @@ int32_t pds_feed_pack(pds_feed *f, int32_t slot, const void *const *signals, con
 
 int32_t pds_feed_submit(pds_feed *f, int32_t slot, const int64_t *lengths, int32_t n_utts, double preemph,
                         int32_t download) {
-  if (!f || slot < 0 || slot >= f->num_slots || n_utts < 0 || (n_utts > 0 && !lengths)) return fail("feed_submit: bad argument");
+  return pds_feed_submit_frames(f, slot, lengths, nullptr, n_utts, -1, preemph, download);
+}
+
+int32_t pds_feed_submit_frames(pds_feed *f, int32_t slot, const int64_t *lengths, const int64_t *nframes, int32_t n_utts,
+                               int32_t pad_left, double preemph, int32_t download) {
+  if (!f || slot < 0 || slot >= f->num_slots || n_utts < 0 || (n_utts > 0 && !lengths) || pad_left < -1)
+    return fail("feed_submit: bad argument");
   Slot &s = f->slots[slot];
   if (s.state != ACQUIRED) return fail("feed_submit: the slot is not acquired");
   if (n_utts > f->slot_utts) return fail("feed_submit: more utterances than the slot holds");
@@ -245,7 +251,8 @@ int32_t pds_feed_submit(pds_feed *f, int32_t slot, const int64_t *lengths, int32
     if (lengths[b] < 0) return fail("feed_submit: negative length");
     off[b] = samples;
     len[b] = lengths[b];
-    nfr[b] = pds_stft_num_frames(f->plan, lengths[b]);
+    nfr[b] = nframes ? nframes[b] : pds_stft_num_frames(f->plan, lengths[b]);
+    if (nfr[b] < 0) return fail("feed_submit: negative frame count");
     row[b] = rows;
     s.h_rows[b] = rows;
     samples += lengths[b];
@@ -285,16 +292,16 @@ int32_t pds_feed_submit(pds_feed *f, int32_t slot, const int64_t *lengths, int32
       for (int64_t b = lo; b < lo + nb; ++b) mx = std::max(mx, nfr[b]);
       const int64_t *d_off = s.d_index + lo, *d_len = s.d_index + SU + lo, *d_nfr = s.d_index + 2 * SU + lo, *d_row = s.d_index + 3 * SU + lo;
       if (format == PDS_SAMPLES_F64)
-        rc = pds_stft_batch_f64in(f->plan, (const double *)src, d_off, d_len, d_nfr, d_row, nb, mx, -1, preemph, feat, 0,
+        rc = pds_stft_batch_f64in(f->plan, (const double *)src, d_off, d_len, d_nfr, d_row, nb, mx, pad_left, preemph, feat, 0,
                                   f->out_cols, s.stream);
       else if (format == PDS_SAMPLES_I16)
-        rc = pds_stft_batch_i16in(f->plan, (const int16_t *)src, d_off, d_len, d_nfr, d_row, nb, mx, -1, preemph, feat,
+        rc = pds_stft_batch_i16in(f->plan, (const int16_t *)src, d_off, d_len, d_nfr, d_row, nb, mx, pad_left, preemph, feat,
                                   f->out_cols, s.stream);
       else if (ragged)
-        rc = pds_stft_batch_ragged_f32(f->plan, (const float *)src, d_off, d_len, d_nfr, d_row, nb, mx, -1, preemph, s.d_work,
+        rc = pds_stft_batch_ragged_f32(f->plan, (const float *)src, d_off, d_len, d_nfr, d_row, nb, mx, pad_left, preemph, s.d_work,
                                        feat, f->out_cols, s.stream);
       else
-        rc = pds_stft_batch_f32(f->plan, (const float *)src, d_off, d_len, d_nfr, d_row, nb, mx, -1, preemph, feat,
+        rc = pds_stft_batch_f32(f->plan, (const float *)src, d_off, d_len, d_nfr, d_row, nb, mx, pad_left, preemph, feat,
                                 f->out_cols, s.stream);
       // (the first piece is refused before anything of it is queued: switch the feed to widened samples and start over)
       if (rc == PDS_ERR_INVALID && lo == 0 && format != PDS_SAMPLES_F32 && attempt == 0) break;

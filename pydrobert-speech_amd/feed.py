@@ -98,12 +98,14 @@ class HostFeed:
         buf = (ctypes.c_char * (self.slot_samples * self.dtype.itemsize)).from_address(ptr.value)
         return slot.value, np.frombuffer(buf, dtype=self.dtype)
 
-    def submit(self, signals: Sequence[np.ndarray], preemphasis: float = 0.0, post=None) -> Ticket:
+    def submit(self, signals: Sequence[np.ndarray], preemphasis: float = 0.0, post=None, nframes=None,
+               pad_left: Optional[int] = None) -> Ticket:
         """Queue one batch of host signals (1-D arrays of the feed's dtype); returns its ticket at once
 
         `post`: optional ``callable(feats, row_offsets) -> tensor`` run on the slot's stream between the kernel
         and the download -- post-processors over the packed rows (``Deltas.apply_rows``, ...); its float32 result
-        (at most ``slot_rows * feature_cols`` elements) is what comes back.
+        (at most ``slot_rows * feature_cols`` elements) is what comes back.  `nframes` / `pad_left`: frames to emit
+        per signal and the left reflection, as ``STFTFrameComputer.launch`` takes them (default: ``compute_full``'s).
         """
         torch = self._torch
         n = len(signals)
@@ -112,7 +114,7 @@ class HostFeed:
         slot, _ = self.acquire()
         ptrs = (ctypes.c_void_p * max(n, 1))(*[a.ctypes.data for a in arrays])
         try:
-            return self._submit(slot, arrays, ptrs, lengths, n, preemphasis, post)
+            return self._submit(slot, arrays, ptrs, lengths, n, preemphasis, post, nframes, pad_left)
         except Exception:
             # the ring hands its slots out in order: pass the slot on as an empty batch instead of losing it
             with torch.cuda.device(self.device):
@@ -120,13 +122,23 @@ class HostFeed:
                     self.collect(Ticket(slot, 0))
             raise
 
-    def _submit(self, slot, arrays, ptrs, lengths, n, preemphasis, post) -> Ticket:
+    def _submit(self, slot, arrays, ptrs, lengths, n, preemphasis, post, nframes=None, pad_left=None) -> Ticket:
         torch = self._torch
         with torch.cuda.device(self.device):
             _native.check(self._lib.pds_feed_pack(self._handle, slot, ptrs, lengths.ctypes.data, n, self.copy_threads),
                           "pds_feed_pack")
-            _native.check(self._lib.pds_feed_submit(self._handle, slot, lengths.ctypes.data, n, float(preemphasis),
-                                                    0 if post is not None else 1), "pds_feed_submit")
+            if nframes is None and pad_left is None:
+                rc = self._lib.pds_feed_submit(self._handle, slot, lengths.ctypes.data, n, float(preemphasis),
+                                               0 if post is not None else 1)
+            else:
+                counts = None if nframes is None else np.ascontiguousarray(nframes, dtype=np.int64).reshape(-1)
+                if counts is not None and counts.shape[0] != n:
+                    raise ValueError("HostFeed.submit: one frame count per signal")
+                rc = self._lib.pds_feed_submit_frames(self._handle, slot, lengths.ctypes.data,
+                                                      None if counts is None else counts.ctypes.data, n,
+                                                      -1 if pad_left is None else int(pad_left), float(preemphasis),
+                                                      0 if post is not None else 1)
+            _native.check(rc, "pds_feed_submit")
             if post is not None:
                 d_ptr, rows, offs, stream = ctypes.c_void_p(), ctypes.c_int64(), ctypes.c_void_p(), ctypes.c_void_p()
                 _native.check(self._lib.pds_feed_device_view(self._handle, slot, ctypes.byref(d_ptr), ctypes.byref(rows),
