@@ -327,8 +327,73 @@ constexpr bool is_pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
 //   Im A[k] =       - sum_j (a[j] - a[M-j]) sin(2 pi j k / M),      j = 1 .. (M - 1) / 2,
 // i.e. about M^2 / 2 fused multiply-adds with literal coefficients: for the M <= 30 in use this
 // is on a par with a mixed-radix network (25: 288 FMA) and has no data movement at all.
+// 25 real points as 5 x 5 (n = 5 n1 + n2, k = k1 + 5 k2): five real 5-point transforms over n1 (outputs k1 = 0, 1, 2;
+// 3 and 4 are their conjugates), the twiddles W_25^(n2 k1), then over n2 one real 5-point transform (k1 = 0: bins 0, 5,
+// 10) and two complex ones (k1 = 1: bins 1, 6, 11 and, conjugated, 9, 4; k1 = 2: bins 2, 7, 12 and 8, 3).  188
+// instructions where the direct evaluation below takes 324.  c1/s1, c2/s2: cos / sin of 72 and 144 degrees.
+#ifndef PDS_RDFT25_MIXED
+#define PDS_RDFT25_MIXED 1
+#endif
+PDS_HD void rdft25(const float *a, float &even_sum, float &odd_sum, float *Ar, float *Ai) {
+  constexpr float c1 = Tw600<5, 1>::re, c2 = Tw600<5, 2>::re, s1 = -Tw600<5, 1>::im, s2 = -Tw600<5, 2>::im;
+  float y0[5], y1r[5], y1i[5], y2r[5], y2i[5];
+  static_for<0, 5>([&](auto nn) {
+    constexpr int n2 = decltype(nn)::value;
+    const float x0 = a[n2], x1 = a[5 + n2], x2 = a[10 + n2], x3 = a[15 + n2], x4 = a[20 + n2];
+    const float p1 = x1 + x4, p2 = x2 + x3, d1 = x1 - x4, d2 = x2 - x3;
+    y0[n2] = x0 + p1 + p2;
+    const float r1 = fmaf(c2, p2, fmaf(c1, p1, x0)), i1 = -fmaf(s2, d2, s1 * d1);
+    const float r2 = fmaf(c1, p2, fmaf(c2, p1, x0)), i2 = fmaf(s1, d2, -(s2 * d1));
+    if constexpr (n2 == 0) {
+      y1r[0] = r1, y1i[0] = i1, y2r[0] = r2, y2i[0] = i2;
+    } else {  // times W_25^(n2 k1)
+      constexpr float w1r = Tw600<25, n2>::re, w1i = Tw600<25, n2>::im, w2r = Tw600<25, 2 * n2>::re, w2i = Tw600<25, 2 * n2>::im;
+      y1r[n2] = fmaf(r1, w1r, -(i1 * w1i));
+      y1i[n2] = fmaf(r1, w1i, i1 * w1r);
+      y2r[n2] = fmaf(r2, w2r, -(i2 * w2i));
+      y2i[n2] = fmaf(r2, w2i, i2 * w2r);
+    }
+  });
+  {  // k1 = 0: real inputs, bins 0, 5, 10
+    const float p1 = y0[1] + y0[4], p2 = y0[2] + y0[3], d1 = y0[1] - y0[4], d2 = y0[2] - y0[3];
+    even_sum = y0[0] + p1 + p2;
+    odd_sum = 0.0f;
+    Ar[5] = fmaf(c2, p2, fmaf(c1, p1, y0[0]));
+    Ai[5] = -fmaf(s2, d2, s1 * d1);
+    Ar[10] = fmaf(c1, p2, fmaf(c2, p1, y0[0]));
+    Ai[10] = fmaf(s1, d2, -(s2 * d1));
+  }
+  auto cdft5 = [&](const float *tr, const float *ti, float *zr, float *zi) {
+    const float p1r = tr[1] + tr[4], p1i = ti[1] + ti[4], p2r = tr[2] + tr[3], p2i = ti[2] + ti[3];
+    const float d1r = tr[1] - tr[4], d1i = ti[1] - ti[4], d2r = tr[2] - tr[3], d2i = ti[2] - ti[3];
+    zr[0] = tr[0] + p1r + p2r;
+    zi[0] = ti[0] + p1i + p2i;
+    const float a1r = fmaf(c2, p2r, fmaf(c1, p1r, tr[0])), a1i = fmaf(c2, p2i, fmaf(c1, p1i, ti[0]));
+    const float a2r = fmaf(c1, p2r, fmaf(c2, p1r, tr[0])), a2i = fmaf(c1, p2i, fmaf(c2, p1i, ti[0]));
+    const float b1r = fmaf(s2, d2r, s1 * d1r), b1i = fmaf(s2, d2i, s1 * d1i);
+    const float b2r = fmaf(-s1, d2r, s2 * d1r), b2i = fmaf(-s1, d2i, s2 * d1i);
+    zr[1] = a1r + b1i, zi[1] = a1i - b1r;  // A1 - i B1
+    zr[4] = a1r - b1i, zi[4] = a1i + b1r;  // A1 + i B1
+    zr[2] = a2r + b2i, zi[2] = a2i - b2r;
+    zr[3] = a2r - b2i, zi[3] = a2i + b2r;
+  };
+  float zr[5], zi[5];
+  cdft5(y1r, y1i, zr, zi);  // bins 1, 6, 11, 16 (= conj of 9), 21 (= conj of 4)
+  Ar[1] = zr[0], Ai[1] = zi[0], Ar[6] = zr[1], Ai[6] = zi[1], Ar[11] = zr[2], Ai[11] = zi[2];
+  Ar[9] = zr[3], Ai[9] = -zi[3], Ar[4] = zr[4], Ai[4] = -zi[4];
+  cdft5(y2r, y2i, zr, zi);  // bins 2, 7, 12, 17 (= conj of 8), 22 (= conj of 3)
+  Ar[2] = zr[0], Ai[2] = zi[0], Ar[7] = zr[1], Ai[7] = zi[1], Ar[12] = zr[2], Ai[12] = zi[2];
+  Ar[8] = zr[3], Ai[8] = -zi[3], Ar[3] = zr[4], Ai[3] = -zi[4];
+}
+
 template <int M>
 PDS_HD void rdft_direct(const float *a, float &even_sum, float &odd_sum, float *Ar, float *Ai) {
+#if PDS_RDFT25_MIXED
+  if constexpr (M == 25) {
+    rdft25(a, even_sum, odd_sum, Ar, Ai);
+    return;
+  }
+#endif
   constexpr int J = (M - 1) / 2;
   constexpr bool EVEN = M % 2 == 0;
   float s[J + 1], d[J + 1];
