@@ -212,10 +212,11 @@ class FeatureDirWriter:
             out_rows["rows"] = rows
             return feats
 
-        ticket = feed.submit(signals, self.pre[0].coeff if self.pre else 0.0, post=post)
-        feats, _ = feed.collect(ticket, copy=True)
+        # (no post-processor: the kernel writes the features into the pinned host buffer itself)
+        ticket = feed.submit(signals, self.pre[0].coeff if self.pre else 0.0, post=post if self.post else None)
+        feats, own_rows = feed.collect(ticket, copy=True)
         feats = torch.from_numpy(feats)
-        rows = out_rows["rows"]
+        rows = out_rows["rows"] if self.post else own_rows
         return [feats[rows[b] : rows[b + 1]].clone() for b in range(len(signals))]
 
     def _postprocess(self, feats, rows):
