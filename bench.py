@@ -66,6 +66,19 @@ WORKLOADS = {
          "use_power": True, "pad_to_nearest_power_of_two": False},
         160000, 1024, None,
     ),
+    # ... 30 ms frames without zero padding (N = L = 480 = 16 x 30)
+    "fbank40_nopad480_b1024x10s": (
+        {"name": "stft", "bank": {"name": "tri", "scaling_function": "mel", "num_filts": 40},
+         "frame_length_ms": 30, "frame_shift_ms": 10, "window_function": "hanning",
+         "use_power": True, "pad_to_nearest_power_of_two": False},
+        160000, 1024, None,
+    ),
+    # 32 ms frames at 16 kHz (L = 512 = N: every one of the 32 rows of the N = 512 geometry in use)
+    "fbank40_16k_32_10_b1024x10s": (
+        {"name": "stft", "bank": {"name": "tri", "scaling_function": "mel", "num_filts": 40},
+         "frame_length_ms": 32, "frame_shift_ms": 10, "window_function": "hanning", "use_power": True},
+        160000, 1024, None,
+    ),
     # 8 kHz telephone speech, the usual 25 ms / 10 ms framing: L = 200 -> N = 256 (32 x 8, eight frames per wave)
     "fbank40_8k_25_10_b1024x10s": (
         {"name": "stft", "bank": {"name": "fbank", "num_filts": 40, "sampling_rate": 8000},
