@@ -66,6 +66,13 @@ WORKLOADS = {
          "use_power": True, "pad_to_nearest_power_of_two": False},
         160000, 1024, None,
     ),
+    # ... 20 ms frames without zero padding (N = L = 320 = 16 x 20)
+    "fbank40_nopad320_b1024x10s": (
+        {"name": "stft", "bank": {"name": "tri", "scaling_function": "mel", "num_filts": 40},
+         "frame_length_ms": 20, "frame_shift_ms": 10, "window_function": "hanning",
+         "use_power": True, "pad_to_nearest_power_of_two": False},
+        160000, 1024, None,
+    ),
     # ... 30 ms frames without zero padding (N = L = 480 = 16 x 30)
     "fbank40_nopad480_b1024x10s": (
         {"name": "stft", "bank": {"name": "tri", "scaling_function": "mel", "num_filts": 40},

@@ -386,11 +386,133 @@ PDS_HD void rdft25(const float *a, float &even_sum, float &odd_sum, float *Ar, f
   Ar[8] = zr[3], Ai[8] = -zi[3], Ar[3] = zr[4], Ai[3] = -zi[4];
 }
 
+// 5-point building blocks of the mixed-radix real transforms below (c1/s1, c2/s2: cos / sin of 72 and 144 degrees;
+// outputs Z[k] = sum_j t[j] e^(-2 pi i j k / 5))
+struct Dft5 {
+  static constexpr float c1 = Tw600<5, 1>::re, c2 = Tw600<5, 2>::re, s1 = -Tw600<5, 1>::im, s2 = -Tw600<5, 2>::im;
+  // real inputs: Z[0] (real), Z[1], Z[2]
+  static PDS_HD void real(const float *y, float &z0, float &z1r, float &z1i, float &z2r, float &z2i) {
+    const float p1 = y[1] + y[4], p2 = y[2] + y[3], d1 = y[1] - y[4], d2 = y[2] - y[3];
+    z0 = y[0] + p1 + p2;
+    z1r = fmaf(c2, p2, fmaf(c1, p1, y[0]));
+    z1i = -fmaf(s2, d2, s1 * d1);
+    z2r = fmaf(c1, p2, fmaf(c2, p1, y[0]));
+    z2i = fmaf(s1, d2, -(s2 * d1));
+  }
+  // complex inputs, the first NOUT outputs (5: all; 2: Z[0], Z[1])
+  template <int NOUT>
+  static PDS_HD void cplx(const float *tr, const float *ti, float *zr, float *zi) {
+    const float p1r = tr[1] + tr[4], p1i = ti[1] + ti[4], p2r = tr[2] + tr[3], p2i = ti[2] + ti[3];
+    const float d1r = tr[1] - tr[4], d1i = ti[1] - ti[4], d2r = tr[2] - tr[3], d2i = ti[2] - ti[3];
+    zr[0] = tr[0] + p1r + p2r;
+    zi[0] = ti[0] + p1i + p2i;
+    const float a1r = fmaf(c2, p2r, fmaf(c1, p1r, tr[0])), a1i = fmaf(c2, p2i, fmaf(c1, p1i, ti[0]));
+    const float b1r = fmaf(s2, d2r, s1 * d1r), b1i = fmaf(s2, d2i, s1 * d1i);
+    zr[1] = a1r + b1i, zi[1] = a1i - b1r;  // A1 - i B1
+    if constexpr (NOUT > 2) {
+      const float a2r = fmaf(c1, p2r, fmaf(c2, p1r, tr[0])), a2i = fmaf(c1, p2i, fmaf(c2, p1i, ti[0]));
+      const float b2r = fmaf(-s1, d2r, s2 * d1r), b2i = fmaf(-s1, d2i, s2 * d1i);
+      zr[4] = a1r - b1i, zi[4] = a1i + b1r;  // A1 + i B1
+      zr[2] = a2r + b2i, zi[2] = a2i - b2r;
+      zr[3] = a2r - b2i, zi[3] = a2i + b2r;
+    }
+  }
+};
+
+// 20 real points as 4 x 5 (n = 5 n1 + n2, k = k1 + 4 k2): five real 4-point transforms over n1 (k1 = 0, 1, 2; 3 is the
+// conjugate of 1), the twiddles W_20^(n2 k1), then over n2 a real 5-point transform (k1 = 0: bins 0, 4, 8), a complex
+// one (k1 = 1: bins 1, 5, 9 and, conjugated, 7, 3) and the first two outputs of another (k1 = 2: bins 2, 6; bin 10 is
+// the alternating sum).  ~140 instructions where the direct evaluation takes ~210.
+PDS_HD void rdft20(const float *a, float &even_sum, float &odd_sum, float *Ar, float *Ai) {
+  float y0[5], y1r[5], y1i[5], y2r[5], y2i[5], alt = 0.0f;
+  static_for<0, 5>([&](auto nn) {
+    constexpr int n2 = decltype(nn)::value;
+    const float x0 = a[n2], x1 = a[5 + n2], x2 = a[10 + n2], x3 = a[15 + n2];
+    const float e0 = x0 + x2, e1 = x0 - x2, o0 = x1 + x3, o1 = x1 - x3;
+    y0[n2] = e0 + o0;
+    const float q = e0 - o0;           // k1 = 2 (real)
+    alt = (n2 % 2 == 0) ? alt + q : alt - q;  // bin 10 = sum_n (-1)^n a[n]
+    if constexpr (n2 == 0) {
+      y1r[0] = e1, y1i[0] = -o1, y2r[0] = q, y2i[0] = 0.0f;
+    } else {
+      constexpr float w1r = Tw600<20, n2>::re, w1i = Tw600<20, n2>::im, w2r = Tw600<20, 2 * n2>::re, w2i = Tw600<20, 2 * n2>::im;
+      y1r[n2] = fmaf(e1, w1r, o1 * w1i);   // (e1 - i o1) (w1r + i w1i)
+      y1i[n2] = fmaf(e1, w1i, -(o1 * w1r));
+      y2r[n2] = q * w2r;
+      y2i[n2] = q * w2i;
+    }
+  });
+  float z0;
+  Dft5::real(y0, z0, Ar[4], Ai[4], Ar[8], Ai[8]);
+  even_sum = 0.5f * (z0 + alt);
+  odd_sum = 0.5f * (z0 - alt);
+  float zr[5], zi[5];
+  Dft5::cplx<5>(y1r, y1i, zr, zi);  // bins 1, 5, 9, 13 (= conj of 7), 17 (= conj of 3)
+  Ar[1] = zr[0], Ai[1] = zi[0], Ar[5] = zr[1], Ai[5] = zi[1], Ar[9] = zr[2], Ai[9] = zi[2];
+  Ar[7] = zr[3], Ai[7] = -zi[3], Ar[3] = zr[4], Ai[3] = -zi[4];
+  Dft5::cplx<2>(y2r, y2i, zr, zi);  // bins 2, 6
+  Ar[2] = zr[0], Ai[2] = zi[0], Ar[6] = zr[1], Ai[6] = zi[1];
+}
+
+// 30 real points as 6 x 5 (n = 5 n1 + n2, k = k1 + 6 k2): five real 6-point transforms over n1 (as 2 x 3; k1 = 0 .. 3,
+// 4 and 5 are conjugates), the twiddles W_30^(n2 k1), then over n2 a real 5-point transform (k1 = 0: bins 0, 6, 12), two
+// complex ones (k1 = 1: bins 1, 7, 13, conjugated 11, 5; k1 = 2: bins 2, 8, 14, conjugated 10, 4) and the first two
+// outputs of a third (k1 = 3: bins 3, 9; bin 15 is the alternating sum).  ~260 instructions instead of ~460.
+PDS_HD void rdft30(const float *a, float &even_sum, float &odd_sum, float *Ar, float *Ai) {
+  constexpr float h3 = 0.86602540378443864676f;  // sin 60
+  float y0[5], y1r[5], y1i[5], y2r[5], y2i[5], y3r[5], y3i[5], alt = 0.0f;
+  static_for<0, 5>([&](auto nn) {
+    constexpr int n2 = decltype(nn)::value;
+    const float x0 = a[n2], x1 = a[5 + n2], x2 = a[10 + n2], x3 = a[15 + n2], x4 = a[20 + n2], x5 = a[25 + n2];
+    // 3-point transforms of the even (x0, x2, x4) and the odd (x1, x3, x5) samples: T0 real, T1 = tr + i ti (T2 = conj T1)
+    const float es = x2 + x4, ed = x2 - x4, os = x3 + x5, od = x3 - x5;
+    const float e0 = x0 + es, e1r = fmaf(-0.5f, es, x0), e1i = -h3 * ed;
+    const float o0 = x1 + os, o1r = fmaf(-0.5f, os, x1), o1i = -h3 * od;
+    y0[n2] = e0 + o0;
+    const float q = e0 - o0;  // k1 = 3 (real)
+    alt = (n2 % 2 == 0) ? alt + q : alt - q;  // bin 15 = sum_n (-1)^n a[n]
+    // k1 = 1: E1 + W6 O1, W6 = 1/2 - i h3;  k1 = 2: conj(E1) + W3 conj(O1), W3 = -1/2 - i h3
+    const float r1 = fmaf(h3, o1i, fmaf(0.5f, o1r, e1r)), i1 = fmaf(-h3, o1r, fmaf(0.5f, o1i, e1i));
+    const float r2 = fmaf(-h3, o1i, fmaf(-0.5f, o1r, e1r)), i2 = fmaf(-h3, o1r, fmaf(0.5f, o1i, -e1i));
+    if constexpr (n2 == 0) {
+      y1r[0] = r1, y1i[0] = i1, y2r[0] = r2, y2i[0] = i2, y3r[0] = q, y3i[0] = 0.0f;
+    } else {
+      constexpr float w1r = Tw600<30, n2>::re, w1i = Tw600<30, n2>::im, w2r = Tw600<30, 2 * n2>::re, w2i = Tw600<30, 2 * n2>::im;
+      constexpr float w3r = Tw600<30, 3 * n2>::re, w3i = Tw600<30, 3 * n2>::im;
+      y1r[n2] = fmaf(r1, w1r, -(i1 * w1i));
+      y1i[n2] = fmaf(r1, w1i, i1 * w1r);
+      y2r[n2] = fmaf(r2, w2r, -(i2 * w2i));
+      y2i[n2] = fmaf(r2, w2i, i2 * w2r);
+      y3r[n2] = q * w3r;
+      y3i[n2] = q * w3i;
+    }
+  });
+  float z0;
+  Dft5::real(y0, z0, Ar[6], Ai[6], Ar[12], Ai[12]);
+  even_sum = 0.5f * (z0 + alt);
+  odd_sum = 0.5f * (z0 - alt);
+  float zr[5], zi[5];
+  Dft5::cplx<5>(y1r, y1i, zr, zi);  // bins 1, 7, 13, 19 (= conj of 11), 25 (= conj of 5)
+  Ar[1] = zr[0], Ai[1] = zi[0], Ar[7] = zr[1], Ai[7] = zi[1], Ar[13] = zr[2], Ai[13] = zi[2];
+  Ar[11] = zr[3], Ai[11] = -zi[3], Ar[5] = zr[4], Ai[5] = -zi[4];
+  Dft5::cplx<5>(y2r, y2i, zr, zi);  // bins 2, 8, 14, 20 (= conj of 10), 26 (= conj of 4)
+  Ar[2] = zr[0], Ai[2] = zi[0], Ar[8] = zr[1], Ai[8] = zi[1], Ar[14] = zr[2], Ai[14] = zi[2];
+  Ar[10] = zr[3], Ai[10] = -zi[3], Ar[4] = zr[4], Ai[4] = -zi[4];
+  Dft5::cplx<2>(y3r, y3i, zr, zi);  // bins 3, 9
+  Ar[3] = zr[0], Ai[3] = zi[0], Ar[9] = zr[1], Ai[9] = zi[1];
+}
+
 template <int M>
 PDS_HD void rdft_direct(const float *a, float &even_sum, float &odd_sum, float *Ar, float *Ai) {
 #if PDS_RDFT25_MIXED
   if constexpr (M == 25) {
     rdft25(a, even_sum, odd_sum, Ar, Ai);
+    return;
+  } else if constexpr (M == 20) {
+    rdft20(a, even_sum, odd_sum, Ar, Ai);
+    return;
+  } else if constexpr (M == 30) {
+    rdft30(a, even_sum, odd_sum, Ar, Ai);
     return;
   }
 #endif
