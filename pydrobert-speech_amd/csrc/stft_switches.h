@@ -115,6 +115,11 @@ extern unsigned long long *g_stamp_buf;  // (stft_fast.hip: pds_debug_set_stamp_
 #ifndef PDS_PACKED_LDS
 #define PDS_PACKED_LDS 0
 #endif
+// row-segment walk: a filter's segments added up with the neighbour's sums as DPP operands of the multiply-adds (1) or
+// through v_mov_b32_dpp + multiply-add (0: rounds 2-3a)
+#ifndef PDS_WALK_DPP_FMAC
+#define PDS_WALK_DPP_FMAC 1
+#endif
 #ifndef PDS_PREEMPH_DPP
 #define PDS_PREEMPH_DPP 1
 #endif

@@ -1682,6 +1682,22 @@ __global__ __launch_bounds__(MAXWAVES * 64, MINW) void stft_wave_kernel(const Fa
         auto shl = [](float v, auto ctrl) {
           return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), decltype(ctrl)::value, 0xf, 0xf, true));
         };
+#if PDS_WALK_DPP_FMAC
+        // the neighbour's sums as DPP operands of the multiply-adds (the compiler keeps a v_mov_b32_dpp per operand: eight
+        // instructions more per round); lanes without a source add 0 (bound_ctrl); a DPP operand must not be read within
+        // two instructions of its last vector write: one s_nop in front, the rest are four instructions apart
+        (void)shl;
+        asm volatile("s_nop 1\n\t"
+                     "v_fmac_f32_dpp %0, %0, %4 row_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+                     "v_fmac_f32_dpp %1, %1, %4 row_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+                     "v_fmac_f32_dpp %2, %2, %4 row_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+                     "v_fmac_f32_dpp %3, %3, %4 row_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+                     "v_fmac_f32_dpp %0, %0, %5 row_shl:2 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+                     "v_fmac_f32_dpp %1, %1, %5 row_shl:2 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+                     "v_fmac_f32_dpp %2, %2, %5 row_shl:2 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+                     "v_fmac_f32_dpp %3, %3, %5 row_shl:2 row_mask:0xf bank_mask:0xf bound_ctrl:0"
+                     : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(m1), "v"(m2));
+#else
         a0 = fmaf(shl(a0, inl::Int<0x101>{}), m1, a0);
         a1 = fmaf(shl(a1, inl::Int<0x101>{}), m1, a1);
         a2 = fmaf(shl(a2, inl::Int<0x101>{}), m1, a2);
@@ -1690,6 +1706,7 @@ __global__ __launch_bounds__(MAXWAVES * 64, MINW) void stft_wave_kernel(const Fa
         a1 = fmaf(shl(a1, inl::Int<0x102>{}), m2, a1);
         a2 = fmaf(shl(a2, inl::Int<0x102>{}), m2, a2);
         a3 = fmaf(shl(a3, inl::Int<0x102>{}), m2, a3);
+#endif
         const int f = (meta >> 16) - 1;  // the filter, on the first lane of its run; -1 elsewhere
         const float vals[4] = {a0, a1, a2, a3};
         TOUT *dst = obase + col0 + (f < 0 ? 0 : f);
