@@ -162,6 +162,15 @@ int32_t pds_stft_batch_ragged_f32(const pds_stft_plan *plan, const float *d_sign
                                   const int64_t *d_nframes, const int64_t *d_row_off, int32_t B,
                                   int64_t max_frames, int32_t pad_left, double preemph,
                                   int64_t *d_workspace, float *d_out, int64_t out_stride, void *stream);
+/* ... for int16 samples (pds_stft_batch_i16in's values).  Stretch scheduling serves float32 samples of every fused
+ * plan whose tables are LDS-resident; with a fused pre-emphasis, and for int16 samples (with or without one), the
+ * row-segment kernels of the transform sizes 512 and 1024 (mel-like banks) -- other plans and calls run the
+ * round-robin order of pds_stft_batch_f32 / _i16in through these entry points, with the same values. */
+int32_t pds_stft_batch_ragged_i16in(const pds_stft_plan *plan, const int16_t *d_signal,
+                                    const int64_t *d_offsets, const int64_t *d_lengths,
+                                    const int64_t *d_nframes, const int64_t *d_row_off, int32_t B,
+                                    int64_t max_frames, int32_t pad_left, double preemph,
+                                    int64_t *d_workspace, float *d_out, int64_t out_stride, void *stream);
 /* Statics AND deltas in one launch (BASELINE.json configs[2]; reference post.py:462-491 applied to
  * compute_full's output along time, "edge" padding): row r of utterance b receives the num_coeffs
  * statics at columns [0, C) and the order-k deltas at [k C, (k + 1) C), k = 1 .. num_deltas.  The

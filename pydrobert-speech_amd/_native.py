@@ -126,6 +126,7 @@ SIGNATURES = {
     "pds_stft_plan_has_i16in": (c_int32, [c_void_p]),
     "pds_stft_batch_i16in": (c_int32, _BATCH_ARGS),
     "pds_stft_batch_ragged_f32": (c_int32, _BATCH_ARGS[:10] + [c_void_p] + _BATCH_ARGS[10:]),
+    "pds_stft_batch_ragged_i16in": (c_int32, _BATCH_ARGS[:10] + [c_void_p] + _BATCH_ARGS[10:]),
     "pds_preemphasize_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_int64, c_double, c_void_p, c_void_p]),
     "pds_preemphasize_f64": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_int64, c_double, c_void_p, c_void_p]),
     "pds_dither_f32": (c_int32, [c_void_p, c_int64, c_double, ctypes.c_uint64, c_void_p, c_void_p]),

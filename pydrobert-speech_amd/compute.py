@@ -490,7 +490,9 @@ class ShortTimeFourierTransformFrameComputer(LinearFilterBankFrameComputer):
                 return lib.pds_stft_batch_f64in(*args[:11], is64, *args[11:])
         elif signal.dtype == torch.float32:
             fn = lib.pds_stft_batch_f32_generic if generic else lib.pds_stft_batch_f32
-            if not generic and not preemphasis and plan.kernel_kind and layout.fill < 0.9 and config.RAGGED_SCHEDULING:
+            # (with a fused pre-emphasis the stretch schedule exists for the row-segment kernels of N = 512 / 1024: the
+            # launch takes it where it can and the round-robin order otherwise, same values)
+            if not generic and plan.kernel_kind and layout.fill < 0.9 and config.RAGGED_SCHEDULING:
                 # (per launch, from the caching allocator: a workspace kept on the layout was shared by launches on
                 # different streams, and chunk_prefix_kernel rewrites it every time)
                 d_work = torch.empty(min(layout.B, _MAX_UTTS_PER_CALL) + 1, dtype=torch.int64, device=signal.device)
@@ -503,6 +505,12 @@ class ShortTimeFourierTransformFrameComputer(LinearFilterBankFrameComputer):
         elif signal.dtype == torch.int16:
             fn = lib.pds_stft_batch_i16in
             out_dtype = torch.float32
+            if layout.fill < 0.9 and config.RAGGED_SCHEDULING:
+                d_work = torch.empty(min(layout.B, _MAX_UTTS_PER_CALL) + 1, dtype=torch.int64, device=signal.device)
+                work = d_work.data_ptr()
+
+                def fn(*args):
+                    return lib.pds_stft_batch_ragged_i16in(*args[:10], work, *args[10:])
         else:
             raise TypeError("signal must be float32, float64 or int16")
         total = layout.total_rows

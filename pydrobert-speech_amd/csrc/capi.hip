@@ -245,6 +245,26 @@ int32_t pds_stft_batch_ragged_f32(const pds_stft_plan *plan, const float *d_sign
   return plan->fast.kind ? pds::launch_stft_fast_f32(plan, a) : pds::launch_stft_generic_f32(plan, a);
 }
 
+int32_t pds_stft_batch_ragged_i16in(const pds_stft_plan *plan, const int16_t *d_signal, const int64_t *d_offsets,
+                                    const int64_t *d_lengths, const int64_t *d_nframes, const int64_t *d_row_off,
+                                    int32_t B, int64_t max_frames, int32_t pad_left, double preemph, int64_t *d_workspace,
+                                    float *d_out, int64_t out_stride, void *stream) {
+  int32_t rc = check_batch(plan, d_signal, d_offsets, d_lengths, d_nframes, d_row_off, B, max_frames, pad_left,
+                           d_out, out_stride);
+  if (rc == 1) return PDS_OK;
+  if (rc != PDS_OK) return rc;
+  if (!pds::fast_has_f64in(plan)) return invalid("stft_batch_ragged_i16in: the plan has no fused int16-input kernel");
+  if (!d_workspace) return invalid("stft_batch_ragged_i16in: null workspace (B + 1 int64 on the device)");
+  rc = pds::check_plan_device(plan->device, "stft_batch");
+  if (rc != PDS_OK) return rc;
+  pds::BatchArgs a{d_signal,   d_offsets, d_lengths,  d_nframes, d_row_off, B, max_frames,
+                   pad_left < 0 ? plan->d.pad_left : pad_left, preemph, d_out, out_stride, (hipStream_t)stream};
+  a.in_i16 = true;
+  a.d_chunk_prefix = d_workspace;
+  a.stretch = true;
+  return pds::launch_stft_fast_f32(plan, a);
+}
+
 int32_t pds_stft_deltas_batch(const pds_stft_plan *plan, const void *d_signal, int32_t signal_is_f64,
                               const int64_t *d_offsets, const int64_t *d_lengths, const int64_t *d_nframes,
                               const int64_t *d_row_off, int32_t B, int64_t max_frames, int32_t pad_left, double preemph,

@@ -270,7 +270,7 @@ int32_t pds_feed_submit_frames(pds_feed *f, int32_t slot, const int64_t *lengths
     PDS_HIP(hipMemcpyAsync(s.d_samples, s.h_samples, (size_t)samples * f->sample_bytes, hipMemcpyHostToDevice, s.stream));
   if (B > 0) PDS_HIP(hipMemcpyAsync(s.d_index, s.h_index, (size_t)4 * SU * sizeof(int64_t), hipMemcpyHostToDevice, s.stream));
   // a batch whose utterances differ in length: stretch scheduling over the chunks that exist (float32 samples)
-  const bool ragged = preemph == 0.0 && B > 0 && longest > 0 && (double)rows < 0.9 * (double)longest * (double)B;
+  const bool ragged = B > 0 && longest > 0 && (double)rows < 0.9 * (double)longest * (double)B;
   for (int attempt = 0; attempt < 2; ++attempt) {
     int32_t format = f->format;
     const void *src = sig;
@@ -294,6 +294,9 @@ int32_t pds_feed_submit_frames(pds_feed *f, int32_t slot, const int64_t *lengths
       if (format == PDS_SAMPLES_F64)
         rc = pds_stft_batch_f64in(f->plan, (const double *)src, d_off, d_len, d_nfr, d_row, nb, mx, pad_left, preemph, feat, 0,
                                   f->out_cols, s.stream);
+      else if (format == PDS_SAMPLES_I16 && ragged)
+        rc = pds_stft_batch_ragged_i16in(f->plan, (const int16_t *)src, d_off, d_len, d_nfr, d_row, nb, mx, pad_left, preemph,
+                                         s.d_work, feat, f->out_cols, s.stream);
       else if (format == PDS_SAMPLES_I16)
         rc = pds_stft_batch_i16in(f->plan, (const int16_t *)src, d_off, d_len, d_nfr, d_row, nb, mx, pad_left, preemph, feat,
                                   f->out_cols, s.stream);

@@ -270,6 +270,20 @@ int32_t launch_wave(const pds_stft_plan *plan, const BatchArgs &a) {
                     : stft_wave_kernel<N1, N2, NROWS, CU_WAVES_K, MINW, true, false, 0, 0, false, float, float, 0, true>;
     p.chunk_prefix = a.d_chunk_prefix;
   }
+  // ... and the flows real ragged batches come in -- fused pre-emphasis, int16 PCM, both -- on the row-segment kernels of
+  // the speech geometries (N = 512 and 1024, mel-like banks); the other banks and sizes keep the round-robin order
+  int strx_which = -1;
+  if constexpr (W4 && (N1 == 32 || N1 == 64) && N2 == 16) {
+    if (a.stretch && (pre || a.in_i16) && !a.in_f64 && a.dl_K == 0 && !mf && a.d_chunk_prefix && in_lds && rsg && !a.d_stat_part) {
+      using I = int16_t;
+      str_used = true;
+      kern = a.in_i16 ? (pre ? stft_wave_kernel<N1, N2, NROWS, CU_WAVES_K, MINW, true, true, 0, 0, true, I, float, 0, true>
+                             : stft_wave_kernel<N1, N2, NROWS, CU_WAVES_K, MINW, true, false, 0, 0, true, I, float, 0, true>)
+                      : stft_wave_kernel<N1, N2, NROWS, CU_WAVES_K, MINW, true, true, 0, 0, true, float, float, 0, true>;
+      p.chunk_prefix = a.d_chunk_prefix;
+      strx_which = a.in_i16 ? (pre ? 38 : 37) : 36;
+    }
+  }
   if (a.d_stat_part) {
     // (the sums are taken where ONE lane holds a coefficient of the item's four frames: the row-segment, segmented
     // and matrix-pipe walks of the 16-lane geometries, tables in LDS)
@@ -312,7 +326,7 @@ int32_t launch_wave(const pds_stft_plan *plan, const BatchArgs &a) {
   // HBM): converted as the frame is loaded, then exactly the float32 kernel; the geometries of the float64-sample
   // path, ELL or row-segment walk, LDS-resident tables
   int i16_which = -1;
-  if (a.in_i16 && a.dl_K == 0) {
+  if (a.in_i16 && a.dl_K == 0 && strx_which < 0) {
     constexpr bool I16IN = fast_f64in_kind(N1 * N2);
     if constexpr (I16IN) {
       if (a.in_f64 || a.out_f64 || a.d_stat_part) {
@@ -378,8 +392,9 @@ int32_t launch_wave(const pds_stft_plan *plan, const BatchArgs &a) {
   // the dynamic-LDS limit is an attribute of the kernel on one device: raised once per
   // (instantiation, device, variant) and remembered (relaxed atomics: a lost race repeats the call)
   constexpr int kDevices = 64;
-  static std::atomic<size_t> attr_smem[kDevices][36];
-  const int which = dl_which >= 0    ? dl_which
+  static std::atomic<size_t> attr_smem[kDevices][40];
+  const int which = strx_which >= 0  ? strx_which
+                    : dl_which >= 0    ? dl_which
                     : f64_which >= 0 ? f64_which
                     : i16_which >= 0 ? i16_which
                     : pf_used        ? (rsg ? 27 : mseg ? 30 : 31)

@@ -634,6 +634,35 @@ def test_alternative_kernel_forms_match_the_oracle(switch, value, name, golden_m
         assert ok, (name, switch, value, b, msg)
 
 
+@pytest.mark.parametrize("flow", ["preemph", "i16", "i16+preemph"])
+@pytest.mark.parametrize("name", ["c2_tri_mel40", "c3_fbank80_energy", "c4_gabor64"])
+def test_ragged_scheduling_with_preemphasis_and_int16_samples(name, flow, golden_meta, monkeypatch):
+    """... for the flows real ragged batches come in: fused pre-emphasis and 16-bit PCM (the row-segment kernels of
+    N = 512 / 1024 have the stretch schedule for them; other banks run the round-robin order through the same entry
+    points) -- same rows as the plain launch, bit for bit"""
+    import torch
+
+    import pydrobert_speech_amd as ps
+
+    comp = alias_factory_subclass_from_arg(FrameComputer, json.loads(json.dumps(golden_meta["configs"][name])))
+    rng = np.random.default_rng(6)
+    S = comp.frame_shift
+    lens = [0, 1, S, 7 * S + 3, 400 * S, 3 * S, 0, 55 * S, 2 * S, 900 * S + 11] + list(rng.integers(0, 60 * S, size=300))
+    host = np.clip(np.rint(3000 * rng.standard_normal(int(np.sum(lens)))), -32768, 32767)
+    x = torch.from_numpy(host.astype("i2" if flow.startswith("i16") else "f4")).cuda()
+    coeff = 0.97 if "preemph" in flow else 0.0
+    offs = np.concatenate([[0], np.cumsum(lens)[:-1]])
+    layout = comp.prepare_layout(offs, lens, device=x.device)
+    assert layout.fill < 0.9
+    monkeypatch.setattr(ps.config, "RAGGED_SCHEDULING", True)
+    a = torch.full((layout.total_rows, comp.num_coeffs), float("nan"), device="cuda")
+    comp.launch(x, layout, out=a, preemphasis=coeff)
+    monkeypatch.setattr(ps.config, "RAGGED_SCHEDULING", False)
+    b = torch.full_like(a, float("nan"))
+    comp.launch(x, layout, out=b, preemphasis=coeff)
+    assert bool(torch.isfinite(a).all()) and torch.equal(a, b)
+
+
 @pytest.mark.parametrize("name", ["c2_tri_mel40", "c4_gabor64", "c5_gammatone64_48k", "c3_fbank80_energy"])
 def test_ragged_scheduling_is_bit_identical(name, golden_meta, monkeypatch):
     """pds_stft_batch_ragged_f32 (every wave one contiguous stretch of the chunks that exist) against the plain

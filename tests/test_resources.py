@@ -38,6 +38,9 @@ DEFAULT_PATH = [
     _key(32, 16, 25, 16, 4),                                  # configs[1]: 40 mel filters, row-segment walk
     _key(32, 16, 25, 16, 4, pre="T"),                         # ... with fused pre-emphasis
     _key(32, 16, 25, 16, 4, str_="T"),                        # ... ragged batches
+    _key(32, 16, 25, 16, 4, str_="T", pre="T"),               # ... with fused pre-emphasis / of 16-bit PCM
+    _key(32, 16, 25, 16, 4, str_="T", tin="s"),
+    _key(32, 16, 25, 16, 4, str_="T", pre="T", tin="s"),
     _key(32, 16, 25, 16, 4, tin="d"),                         # ... float64 samples
     _key(32, 16, 25, 16, 4, tin="d", tout="d"),
     _key(32, 16, 25, 16, 4, pre="T", tin="d"),                # the reference drivers' flow: float64 audio, pre-emphasis
@@ -69,14 +72,14 @@ def test_default_path_kernels_have_no_scratch():
 
 
 def test_instantiation_matrix_stays_bounded():
-    """ product build: fewer than 270 instantiations of the fused kernel (222 without the 46
-    int16-sample ones that came after that item), device code below 4.1 MB (3.4 MB without them), and no kernel
+    """ product build: fewer than 290 instantiations of the fused kernel (228 without the 58
+    int16-sample ones that came after that item), device code below 4.3 MB (3.5 MB without them), and no kernel
     anywhere in the library with more than 40 spilled registers"""
     table, text = _table()
     stft = [k for k in table if k.startswith("stft_wave<")]
-    assert 0 < len(stft) < 270, len(stft)
-    assert text < 4.1e6, text
+    assert 0 < len(stft) < 290, len(stft)
+    assert text < 4.3e6, text
     int16 = [k for k in stft if "TIN=s" in k]
-    assert 0 < len(int16) <= 46 and len(stft) - len(int16) < 225, (len(int16), len(stft))
+    assert 0 < len(int16) <= 58 and len(stft) - len(int16) < 232, (len(int16), len(stft))
     worst = max(table.values(), key=lambda k: k.get("vgpr_spill_count", 0))
     assert worst.get("vgpr_spill_count", 0) <= 40, worst
