@@ -172,3 +172,27 @@ def test_compute_full_of_one_host_signal_goes_through_a_small_direct_feed(golden
         w = comp.compute_full(x)
         assert g.dtype == w.dtype == np.float32 and g.shape == w.shape
         np.testing.assert_array_equal(g, w)
+
+
+def test_feed_views_of_the_pinned_buffers_and_an_early_stop(golden_meta):
+    """run(copy=False): the arrays are views of the slot's pinned buffer, valid until the generator is advanced; a
+    consumer that stops early leaves the ring drained and usable"""
+    import torch
+
+    comp = build(golden_meta["configs"]["c2_tri_mel40"])
+    rng = np.random.default_rng(16)
+    batches = batches_of(rng, np.float32, 6, 4, 5000)
+    with HostFeed(comp, np.float32, slot_samples=30000, slot_utts=8, slots=3) as feed:
+        seen = []
+        for k, feats in enumerate(feed.run(batches, copy=False)):
+            seen.append([f.copy() for f in feats])  # (the views die with the next iteration)
+            if k == 2:
+                break  # three batches are still in flight / unsent
+        again = list(feed.run(batches[:2]))  # the ring is free again
+    for batch, feats in list(zip(batches, seen)) + list(zip(batches[:2], again)):
+        lens = [len(x) for x in batch]
+        offs = np.concatenate([[0], np.cumsum(lens)[:-1]])
+        want, rows = comp.compute_packed(torch.from_numpy(np.concatenate(batch)).cuda(), offs, lens)
+        want = want.cpu().numpy()
+        for b in range(len(batch)):
+            np.testing.assert_array_equal(feats[b], want[rows[b] : rows[b + 1]])
