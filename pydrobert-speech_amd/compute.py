@@ -12,6 +12,7 @@ MI355X; there is no CPU path in this module.
 import abc
 import ctypes
 import os
+import threading
 from typing import List, Mapping, Optional, Sequence, Tuple, Union
 
 import numpy as np
@@ -317,6 +318,7 @@ class ShortTimeFourierTransformFrameComputer(LinearFilterBankFrameComputer):
         )
         self._plans = {}  # device index -> _NativePlan (tables live on one GPU)
         self._feeds = {}  # (device index, sample dtype) -> feed.HostFeed of compute_full_batch
+        self._feed_lock = threading.Lock()  # a staging ring has one feeding thread: others take the plain path
         self._reset_stream()
 
     # ---- properties ---------------------------------------------------------------
@@ -773,18 +775,23 @@ class ShortTimeFourierTransformFrameComputer(LinearFilterBankFrameComputer):
         plan = self._native_plan()
         if not plan.kernel_kind or (f64 and not plan.has_f64in):
             return None
-        key = (torch.cuda.current_device(), np.dtype(in_dtype), "one")
-        feed = self._feeds.get(key)
-        if feed is None or feed.slot_samples < n:
-            if feed is not None:
-                feed.close()
-            size = 1 << 20
-            while size < n:
-                size <<= 1
-            feed = self._feeds[key] = HostFeed(self, in_dtype, slot_samples=size, slot_utts=1, slots=1, copy_threads=2)
-        if nframes > feed.slot_rows:
-            return None
-        feats, _ = feed.collect(feed.submit([signal], nframes=[nframes], pad_left=pad_left))
+        if not self._feed_lock.acquire(blocking=False):
+            return None  # (another thread is in a staging ring of this computer: the plain path has no shared state)
+        try:
+            key = (torch.cuda.current_device(), np.dtype(in_dtype), "one")
+            feed = self._feeds.get(key)
+            if feed is None or feed.slot_samples < n:
+                if feed is not None:
+                    feed.close()
+                size = 1 << 20
+                while size < n:
+                    size <<= 1
+                feed = self._feeds[key] = HostFeed(self, in_dtype, slot_samples=size, slot_utts=1, slots=1, copy_threads=2)
+            if nframes > feed.slot_rows:
+                return None
+            feats, _ = feed.collect(feed.submit([signal], nframes=[nframes], pad_left=pad_left))
+        finally:
+            self._feed_lock.release()
         return feats if feats.dtype == in_dtype else feats.astype(in_dtype)
 
     def _full_batch_through_feed(self, signals, lengths, in_dtype, preemphasis):
@@ -804,35 +811,48 @@ class ShortTimeFourierTransformFrameComputer(LinearFilterBankFrameComputer):
         plan = self._native_plan()
         if not plan.kernel_kind or (f64 and not plan.has_f64in):
             return None
-        key = (torch.cuda.current_device(), np.dtype(in_dtype))
-        feed = self._feeds.get(key)
-        if feed is None:
-            feed = self._feeds[key] = HostFeed(self, in_dtype, slot_samples=_FEED_SLOT_SAMPLES, slot_utts=_FEED_SLOT_UTTS,
-                                               slots=3, copy_threads=min(16, os.cpu_count() or 1))
-        # slot-sized runs of consecutive utterances
-        pieces, lo, acc = [], 0, 0
-        for b, n in enumerate(lengths):
-            if b > lo and (acc + n > _FEED_SLOT_SAMPLES or b - lo >= _FEED_SLOT_UTTS):
-                pieces.append((lo, b))
-                lo, acc = b, 0
-            acc += n
-        pieces.append((lo, len(lengths)))
-        rows = np.zeros(len(lengths) + 1, dtype=np.int64)
-        np.cumsum([self.num_frames(n) for n in lengths], out=rows[1:])
-        C = self.num_coeffs
-        out = np.empty((int(rows[-1]), C), dtype=np.float32)
-        pending = []
+        if not self._feed_lock.acquire(blocking=False):
+            return None
+        try:
+            key = (torch.cuda.current_device(), np.dtype(in_dtype))
+            feed = self._feeds.get(key)
+            if feed is None:
+                feed = self._feeds[key] = HostFeed(self, in_dtype, slot_samples=_FEED_SLOT_SAMPLES, slot_utts=_FEED_SLOT_UTTS,
+                                                   slots=3, copy_threads=min(16, os.cpu_count() or 1))
+            # slot-sized runs of consecutive utterances
+            pieces, lo, acc = [], 0, 0
+            for b, n in enumerate(lengths):
+                if b > lo and (acc + n > _FEED_SLOT_SAMPLES or b - lo >= _FEED_SLOT_UTTS):
+                    pieces.append((lo, b))
+                    lo, acc = b, 0
+                acc += n
+            pieces.append((lo, len(lengths)))
+            rows = np.zeros(len(lengths) + 1, dtype=np.int64)
+            np.cumsum([self.num_frames(n) for n in lengths], out=rows[1:])
+            C = self.num_coeffs
+            out = np.empty((int(rows[-1]), C), dtype=np.float32)
+            pending = []
 
-        def drain():
-            ticket, (a, _) = pending.pop(0)
-            feed.collect_into(ticket, out[rows[a]:])
+            def drain():
+                ticket, (a, _) = pending.pop(0)
+                feed.collect_into(ticket, out[rows[a]:])
 
-        for piece in pieces:
-            if len(pending) >= feed.slots - 1:
-                drain()
-            pending.append((feed.submit(signals[piece[0] : piece[1]], preemphasis), piece))
-        while pending:
-            drain()
+            try:
+                for piece in pieces:
+                    if len(pending) >= feed.slots - 1:
+                        drain()
+                    pending.append((feed.submit(signals[piece[0] : piece[1]], preemphasis), piece))
+                while pending:
+                    drain()
+            except BaseException:
+                for ticket, _ in pending:  # (leave the ring free for the next call)
+                    try:
+                        feed.collect(ticket, copy=False)
+                    except Exception:
+                        pass
+                raise
+        finally:
+            self._feed_lock.release()
         if out.dtype != in_dtype:
             out = out.astype(in_dtype)
         return [out[rows[b] : rows[b + 1]] for b in range(len(lengths))]

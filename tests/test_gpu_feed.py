@@ -196,3 +196,18 @@ def test_feed_views_of_the_pinned_buffers_and_an_early_stop(golden_meta):
         want = want.cpu().numpy()
         for b in range(len(batch)):
             np.testing.assert_array_equal(feats[b], want[rows[b] : rows[b + 1]])
+
+
+def test_compute_full_from_several_threads_at_once(golden_meta):
+    """compute_full touches no state of the computer (reference compute.py:574-607): threads may call it at once -- one
+    of them is in the staging ring, the others take the plain path; every result is the single-threaded one"""
+    import concurrent.futures
+
+    comp = build(golden_meta["configs"]["c2_tri_mel40"])
+    rng = np.random.default_rng(17)
+    sigs = [(3000 * rng.standard_normal(n)).astype(np.float32) for n in rng.integers(2000, 40000, size=24)]
+    want = [comp.compute_full(x) for x in sigs]
+    with concurrent.futures.ThreadPoolExecutor(6) as pool:
+        got = list(pool.map(comp.compute_full, sigs * 3))
+    for k, g in enumerate(got):
+        np.testing.assert_array_equal(g, want[k % len(sigs)])
