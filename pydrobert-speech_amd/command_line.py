@@ -7,9 +7,12 @@ Same command line and on-disk result as the reference's tool -- a text map of
 * signals are read by a pool of host threads (``--num-workers``) while the GPU works on the
   previous batch; 16-bit PCM stays int16 until a frame is loaded on the device (a quarter of the
   bytes of the reference's float64 arrays over PCIe; the conversion is exact);
-* a batch goes through the pinned staging ring of ``feed.HostFeed`` where the chain allows (an STFT
-  computer with a fused kernel, at most a pre-emphasis in front): upload, kernels and download are
-  queued on one stream without a host concatenate or a pageable copy;
+* with ``--staging-ring`` a batch goes through the pinned staging ring of ``feed.HostFeed`` where the
+  chain allows (an STFT computer with a fused kernel, at most a pre-emphasis in front): upload,
+  kernels and download are queued on one stream without a host concatenate or a pageable copy.  Off
+  by default: the tool is bound by reading and writing files (~1 ms per utterance against ~10 us of
+  device work), and on a corpus of a thousand utterances the ring's pinned buffers cost more to set
+  up than they save (tools/driver_rate.py: 0.6-0.9 s without, 1.4-2.1 s with);
 * a batch of utterances (``--batch-utts`` / ``--batch-samples``) is packed into one device
   buffer and goes through ONE launch per stage: dither, pre-emphasis (fused into the frame
   loader when it is the last pre-processor), the fused STFT/filter-bank kernel, then each
@@ -88,6 +91,8 @@ def _parse(args):
     ap.add_argument("--batch-utts", type=int, default=256, help="utterances per device batch")
     ap.add_argument("--batch-samples", type=int, default=1 << 26, help="samples per device batch")
     ap.add_argument("--precision", choices=("float32", "float64"), default="float32")
+    ap.add_argument("--staging-ring", action="store_true",
+                    help="send the batches through a pinned staging ring (feed.HostFeed); pays on very large corpora only")
     return ap.parse_args(args)
 
 
@@ -103,7 +108,7 @@ class FeatureDirWriter:
     def __init__(self, computer: Optional[FrameComputer], preprocessors: Sequence[PreProcessor],
                  postprocessors: Sequence[PostProcessor], out_dir: str, channel: int = -1,
                  force_as: Optional[str] = None, seed: int = 0, file_prefix: str = "",
-                 file_suffix: str = ".pt", manifest=None, precision: str = "float32"):
+                 file_suffix: str = ".pt", manifest=None, precision: str = "float32", staging_ring: bool = False):
         for pre in preprocessors:
             if not isinstance(pre, (Dither, Preemphasize)):
                 raise NotImplementedError(f"pre-processor {type(pre).__name__}")
@@ -111,6 +116,7 @@ class FeatureDirWriter:
         self.out_dir, self.channel, self.force_as, self.seed = out_dir, channel, force_as, seed
         self.prefix, self.suffix, self.manifest = file_prefix, file_suffix, manifest
         self.dtype = np.dtype(precision)
+        self.staging_ring = bool(staging_ring)
         self._feeds = {}  # sample dtype -> HostFeed
         os.makedirs(out_dir, exist_ok=True)
 
@@ -181,8 +187,12 @@ class FeatureDirWriter:
 
         from .feed import HostFeed
 
+        from . import config
+
         comp = self.computer
         if comp is None or self.dtype != np.float32 or not getattr(comp, "fuses_preemphasis", False) or not len(signals):
+            return None
+        if not (self.staging_ring and config.HOST_FEED):
             return None
         if len(self.pre) > 1 or (self.pre and not isinstance(self.pre[0], Preemphasize)) or not int(lengths.sum()):
             return None
@@ -332,7 +342,7 @@ def signals_to_torch_feat_dir(args=None) -> int:
     writer = FeatureDirWriter(
         computer, _as_list(options.preprocess, PreProcessor), _as_list(options.postprocess, PostProcessor),
         options.dir, options.channel, options.force_as, seed, options.file_prefix, options.file_suffix,
-        options.manifest, options.precision,
+        options.manifest, options.precision, options.staging_ring,
     )
     writer.run(list(utt2path.items()), options.batch_utts, options.batch_samples, options.num_workers)
     return 0

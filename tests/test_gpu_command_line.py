@@ -156,8 +156,9 @@ def test_short_integration_computer_config(tmp_path, with_preemph):
 
 
 def test_pcm_files_travel_as_int16_through_the_staging_ring(tmp_path, monkeypatch):
-    """A corpus of 16-bit WAV files: the samples stay int16 on the host and over PCIe (feed.HostFeed with int16
-    slots, pds_stft_batch_i16in), and the feature files equal those of the float32 pipeline"""
+    """A corpus of 16-bit WAV files with --staging-ring: the samples stay int16 on the host and over PCIe
+    (feed.HostFeed with int16 slots, pds_stft_batch_i16in), and the feature files equal those of the float32
+    pipeline; without the flag (the default) the same files come out of the plain batches"""
     import torch
 
     from pydrobert_speech_amd import feed as feed_mod
@@ -187,7 +188,7 @@ def test_pcm_files_travel_as_int16_through_the_staging_ring(tmp_path, monkeypatc
     out = str(tmp_path / "feats")
     rc = signals_to_torch_feat_dir([
         map_path, json.dumps(FBANK), out, "--preprocess", json.dumps([{"name": "preemph", "coeff": 0.97}]),
-        "--postprocess", json.dumps([{"name": "deltas", "num_deltas": 2}]), "--batch-utts", "2",
+        "--postprocess", json.dumps([{"name": "deltas", "num_deltas": 2}]), "--batch-utts", "2", "--staging-ring",
     ])
     assert rc == 0 and made and all(d == np.int16 for d in made)
     comp = alias_factory_subclass_from_arg(FrameComputer, dict(FBANK))
@@ -196,3 +197,14 @@ def test_pcm_files_travel_as_int16_through_the_staging_ring(tmp_path, monkeypatc
         want = Deltas(2).apply(comp.compute_full(Preemphasize(0.97).apply(x.astype("f4"))), axis=-1)
         assert got.shape == want.shape, utt
         assert np.allclose(got, want, rtol=2e-4, atol=2e-4), (utt, np.abs(got - want).max())
+    made.clear()
+    plain = str(tmp_path / "feats_plain")
+    rc = signals_to_torch_feat_dir([
+        map_path, json.dumps(FBANK), plain, "--preprocess", json.dumps([{"name": "preemph", "coeff": 0.97}]),
+        "--postprocess", json.dumps([{"name": "deltas", "num_deltas": 2}]), "--batch-utts", "2",
+    ])
+    assert rc == 0 and not made
+    for utt in sigs:
+        a = torch.load(os.path.join(out, f"{utt}.pt"), weights_only=True)
+        b = torch.load(os.path.join(plain, f"{utt}.pt"), weights_only=True)
+        assert a.shape == b.shape and torch.allclose(a, b, rtol=1e-5, atol=1e-5), utt
