@@ -54,7 +54,8 @@ class HostFeed:
         self.dtype = np.dtype(dtype)
         if self.dtype not in _FORMATS:
             raise TypeError("HostFeed: samples must be float32, float64 or int16")
-        self.computer = computer
+        # (no reference to the computer itself: it keeps its feeds in a dict, and a cycle would leave their pinned
+        # buffers to the cyclic collector)
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
         self._plan = computer._native_plan(self.device)  # (kept alive: the feed uses its tables)
         self.slot_samples, self.slot_utts, self.slots = int(slot_samples), int(slot_utts), int(slots)
