@@ -11,7 +11,7 @@ cd /root/repo/pydrobert-speech_amd/csrc
 name=$1; shift
 mkdir -p /root/repo/variants /tmp/variant_$name
 flags="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wall -Wno-unused-result -ffp-contract=fast -fno-slp-vectorize"
-others="capi stft_generic post pre si si_fft comm"
+others="capi stft_generic post pre si si_fft comm feed"
 if [ -n "$VARIANT_SRC" ]; then
   u=${VARIANT_SRC%.hip}
   /opt/rocm/bin/hipcc $flags "$@" -c $VARIANT_SRC -o /tmp/variant_$name/$u.o
