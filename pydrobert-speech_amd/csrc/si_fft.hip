@@ -36,7 +36,7 @@ namespace {
 
 constexpr int kN = 1024, kL = 32;       // transform size; lanes = registers = 32
 constexpr int kRowStride = kL + 1;      // exchange row stride in float2: conflict-free both ways
-constexpr int kWaves = 4;               // wavefronts per workgroup, two transforms each
+constexpr int kWaves = 8;               // wavefronts per workgroup (two per SIMD), two transforms each
 constexpr int kMaxBlocks = 8;           // shift-sized blocks a transform may yield (register budget)
 
 // x + (x of the lane a DPP control word selects inside the 16-lane row)
@@ -64,17 +64,17 @@ __device__ __forceinline__ void half_wave_sync() {
 }
 
 // (zr, zi)[q] = element 32 q + l  ->  (zr, zi)[q] = bin 32 q + l of the 1024-point DFT
-// (twr, twi)[q] = W_1024^(l q): the lane's twiddles live in registers -- with one wave per SIMD
-// there are 512 of them, and an LDS table read would be ordered against the transposition writes
-__device__ __forceinline__ void fft1024(float (&zr)[kL], float (&zi)[kL], float2 *xch,
-                                        const float (&twr)[kL], const float (&twi)[kL], int l) {
+// tw[q * 32 + l] = W_1024^(l q), in LDS: two waves share a SIMD, so a wave has 256 registers and
+// the table's reads are covered by the other wave
+__device__ __forceinline__ void fft1024(float (&zr)[kL], float (&zi)[kL], float2 *xch, const float2 *tw, int l) {
   float ar[kL], ai[kL];
   inl::CFFT<kL, 1>::run(zr, zi, ar, ai);
 #pragma unroll
   for (int q = 0; q < kL; ++q) {
+    const float2 t = tw[q * kL + l];
     float2 v;
-    v.x = ar[q] * twr[q] - ai[q] * twi[q];
-    v.y = ar[q] * twi[q] + ai[q] * twr[q];
+    v.x = ar[q] * t.x - ai[q] * t.y;
+    v.y = ar[q] * t.y + ai[q] * t.x;
     xch[q * kRowStride + l] = v;
   }
   half_wave_sync();
@@ -96,16 +96,21 @@ __device__ __forceinline__ void fft1024(float (&zr)[kL], float (&zi)[kL], float2
 // half), so both directions cost one exchange between the halves and one twiddle multiply more
 // than the 1024-point form.  It serves filter supports up to 2048 - S taps and is also chosen for
 // shorter ones when it wastes less of each transform on the overlap.
-template <bool BIG>
+//
+// NW: window factors a lane keeps per window half -- the lane sums samples lt, lt + LANES, ... of
+// every block, and the window repeats from block to block, so ceil(S / LANES) <= NW factors per half
+// weight all of them.
+template <bool BIG, int NW>
 __global__ __launch_bounds__(kWaves * 64, 1) void si_fft_kernel(const SiFftArgs p) {
   constexpr int NT = BIG ? 2 * kN : kN;
+  constexpr int LANES = BIG ? 64 : kL;     // lanes of one transform
   extern __shared__ __attribute__((aligned(16))) unsigned char si_fft_smem[];
   float2 *xch_all = reinterpret_cast<float2 *>(si_fft_smem);          // [2 kWaves][32][33]
-  float *wexp = reinterpret_cast<float *>(xch_all + 2 * kWaves * kL * kRowStride);  // [2][V]: window halves, periodic
-  const int V = p.blocks * p.S;
-  for (int i = threadIdx.x; i < V; i += kWaves * 64) {
-    wexp[i] = p.window[i % p.S];
-    wexp[V + i] = p.window[p.S + i % p.S];
+  float2 *tw = xch_all + 2 * kWaves * kL * kRowStride;                // [32][32]
+  float2 *tw2 = tw + kL * kL;                                         // [32][32] (BIG)
+  for (int i = threadIdx.x; i < kL * kL; i += kWaves * 64) {
+    tw[i] = p.twiddle[i];
+    if constexpr (BIG) tw2[i] = p.twiddle2k[i];
   }
   __syncthreads();
   const int half = threadIdx.x >> 5;       // 0 .. 2 kWaves - 1: one FFT-1024 each
@@ -114,6 +119,7 @@ __global__ __launch_bounds__(kWaves * 64, 1) void si_fft_kernel(const SiFftArgs 
   const int lt = BIG ? (threadIdx.x & 63) : l;  // lane within the transform
   float2 *xch = xch_all + half * kL * kRowStride;
   const int b = blockIdx.y;
+  const int V = p.blocks * p.S;
   const int64_t Tb = p.nframes[b];
   const int64_t num_dft = (Tb + 1 + p.blocks - 1) / p.blocks;  // frames need blocks 0 .. Tb
   const int64_t d = BIG ? (int64_t)blockIdx.x * kWaves + (half >> 1) : (int64_t)blockIdx.x * (2 * kWaves) + half;
@@ -130,21 +136,14 @@ __global__ __launch_bounds__(kWaves * 64, 1) void si_fft_kernel(const SiFftArgs 
   // sample held in register q (time layout) and bin held in register q (frequency layout)
   auto sample_of = [&](int q) { return BIG ? 64 * q + 2 * l + hw : kL * q + l; };
   auto bin_of = [&](int q) { return BIG ? kN * hw + kL * q + l : kL * q + l; };
-  float twr[kL], twi[kL], wa[kL], wb[kL];  // loop invariants of the lane (see fft1024)
-  float t2r[BIG ? kL : 1], t2i[BIG ? kL : 1];  // W_2048^(32 q + l)
+  // window factors of the samples lt + LANES j of a block (0 past the block's end: those reads
+  // land in the next block or behind the last one and are weighted away)
+  float wa[NW], wb[NW];
 #pragma unroll
-  for (int q = 0; q < kL; ++q) {
-    const float2 t = p.twiddle[q * kL + l];
-    twr[q] = t.x;
-    twi[q] = t.y;
-    if constexpr (BIG) {
-      const float2 t2 = p.twiddle2k[q * kL + l];
-      t2r[q] = t2.x;
-      t2i[q] = t2.y;
-    }
-    const int m = sample_of(q) - first_valid;  // position inside the V filtered samples
-    wa[q] = m >= 0 ? wexp[m] : 0.0f;
-    wb[q] = m >= 0 ? wexp[V + m] : 0.0f;
+  for (int j = 0; j < NW; ++j) {
+    const int m = lt + LANES * j;
+    wa[j] = m < p.S ? p.window[m] : 0.0f;
+    wb[j] = m < p.S ? p.window[p.S + m] : 0.0f;
   }
   float zr[kL], zi[kL];
 #pragma unroll
@@ -153,13 +152,14 @@ __global__ __launch_bounds__(kWaves * 64, 1) void si_fft_kernel(const SiFftArgs 
     zr[q] = (has_work && idx >= 0 && idx < n) ? x[idx] : 0.0f;
     zi[q] = 0.0f;
   }
-  fft1024(zr, zi, xch, twr, twi, l);
+  fft1024(zr, zi, xch, tw, l);
   if constexpr (BIG) {
     // X[j] = E[j] + W^j O[j] (lower half), X[j + 1024] = E[j] - W^j O[j] (upper half)
 #pragma unroll
     for (int q = 0; q < kL; ++q) {
-      const float ur = hw ? zr[q] * t2r[q] - zi[q] * t2i[q] : zr[q];
-      const float ui = hw ? zr[q] * t2i[q] + zi[q] * t2r[q] : zi[q];
+      const float2 t2 = tw2[q * kL + l];
+      const float ur = hw ? zr[q] * t2.x - zi[q] * t2.y : zr[q];
+      const float ui = hw ? zr[q] * t2.y + zi[q] * t2.x : zi[q];
       const float pr = __shfl_xor(ur, 32, 64), pi = __shfl_xor(ui, 32, 64);
       zr[q] = hw ? pr - ur : ur + pr;
       zi[q] = hw ? pi - ui : ui + pi;
@@ -171,11 +171,13 @@ __global__ __launch_bounds__(kWaves * 64, 1) void si_fft_kernel(const SiFftArgs 
     xr[q] = zr[q];
     xi[q] = zi[q];
   }
-  // [2][V] after the last transposition of a filter (2048-point form: the wave's two areas)
+  // |y|^2 of the V filtered samples (+ one dump slot) after the last transposition of a filter
+  // (2048-point form: the wave's two areas, contiguous)
   float *zw = reinterpret_cast<float *>(BIG ? xch_all + (half & ~1) * kL * kRowStride : xch);
+  const float *zl = zw + lt;
   float *srow = p.scratch + ((int64_t)b * p.blocks_per_utt + d * p.blocks) * p.C * 2;
-  // the filter's spectrum is fetched one filter ahead: 32 loads in flight under the transform of
-  // the filter before instead of 32 round trips in front of this one
+  // the filter's spectrum is fetched while the block sums of the filter before are formed: by then
+  // the transform's registers are free, and the loads land under the sums
   float hr[kL], hi[kL];
 #pragma unroll
   for (int q = 0; q < kL; ++q) {
@@ -191,6 +193,31 @@ __global__ __launch_bounds__(kWaves * 64, 1) void si_fft_kernel(const SiFftArgs 
       zr[q] = xr[q] * hr[q] - xi[q] * hi[q];
       zi[q] = -(xr[q] * hi[q] + xi[q] * hr[q]);
     }
+    PDS_SI_PHASE();
+    if constexpr (BIG) {
+      // a[j] = Z[j] + Z[j + 1024] (lower half), b[j] = (Z[j] - Z[j + 1024]) W^j (upper half)
+#pragma unroll
+      for (int q = 0; q < kL; ++q) {
+        const float2 t2 = tw2[q * kL + l];
+        const float pr = __shfl_xor(zr[q], 32, 64), pi = __shfl_xor(zi[q], 32, 64);
+        const float dr = pr - zr[q], di = pi - zi[q];
+        zr[q] = hw ? dr * t2.x - di * t2.y : zr[q] + pr;
+        zi[q] = hw ? dr * t2.y + di * t2.x : zi[q] + pi;
+      }
+    }
+    fft1024(zr, zi, xch, tw, l);
+    PDS_SI_PHASE();
+    // |y|^2 (the conjugation does not matter) -> LDS; samples before the alias-free part go to a
+    // dump slot behind the array (no branches in this loop)
+#pragma unroll
+    for (int q = 0; q < kL; ++q) {
+      const int m = sample_of(q) - first_valid;  // position inside the V filtered samples
+      float z = zr[q] * zr[q] + zi[q] * zi[q];
+      if (!p.use_power) z = __builtin_amdgcn_sqrtf(z);
+      zw[m >= 0 ? m : V] = z;
+    }
+    half_wave_sync();
+    PDS_SI_PHASE();
     {
       const float2 *h = p.spectra + (size_t)(c + 1 < p.C ? c + 1 : c) * NT;
 #pragma unroll
@@ -200,40 +227,23 @@ __global__ __launch_bounds__(kWaves * 64, 1) void si_fft_kernel(const SiFftArgs 
         hi[q] = hs.y;
       }
     }
-    if constexpr (BIG) {
-      // a[j] = Z[j] + Z[j + 1024] (lower half), b[j] = (Z[j] - Z[j + 1024]) W^j (upper half)
-#pragma unroll
-      for (int q = 0; q < kL; ++q) {
-        const float pr = __shfl_xor(zr[q], 32, 64), pi = __shfl_xor(zi[q], 32, 64);
-        const float dr = pr - zr[q], di = pi - zi[q];
-        zr[q] = hw ? dr * t2r[q] - di * t2i[q] : zr[q] + pr;
-        zi[q] = hw ? dr * t2i[q] + di * t2r[q] : zi[q] + pi;
-      }
-    }
-    fft1024(zr, zi, xch, twr, twi, l);
-    PDS_SI_PHASE();
-    // |y|^2 (the conjugation does not matter) times the two window halves -> LDS; samples before
-    // the alias-free part go to a dump slot behind the two arrays (no branches in this loop)
-#pragma unroll
-    for (int q = 0; q < kL; ++q) {
-      const int m = sample_of(q) - first_valid;  // position inside the V filtered samples
-      float z = zr[q] * zr[q] + zi[q] * zi[q];
-      if (!p.use_power) z = __builtin_amdgcn_sqrtf(z);
-      zw[m >= 0 ? m : 2 * V] = z * wa[q];
-      zw[m >= 0 ? V + m : 2 * V] = z * wb[q];
-    }
-    half_wave_sync();
-    // every lane first gathers its share of all 2 * blocks sums (independent LDS reads), then the
-    // 32-lane butterflies of all of them run side by side: four DPP steps inside the 16-lane rows
-    // and one exchange between the two rows of the half-wave
-    PDS_SI_PHASE();
+    // every lane weights its share of every block with the two window halves (independent LDS
+    // reads), then the butterflies of all 2 * blocks sums run side by side: four DPP steps inside
+    // the 16-lane rows and one exchange between the two rows of the half-wave
     float part[2 * kMaxBlocks];
 #pragma unroll
-    for (int task = 0; task < 2 * kMaxBlocks; ++task) {
-      part[task] = 0.0f;
-      if (task < 2 * p.blocks) {
-        const float *src = zw + (task & 1) * V + (task >> 1) * p.S;
-        for (int m = lt; m < p.S; m += (BIG ? 64 : kL)) part[task] += src[m];
+    for (int k = 0; k < kMaxBlocks; ++k) {
+      part[2 * k] = 0.0f;
+      part[2 * k + 1] = 0.0f;
+      if (k < p.blocks) {
+        const float *src = zl + k * p.S;
+#pragma unroll
+        for (int j = 0; j < NW; ++j)
+          if (j * LANES < p.S) {
+            const float z = src[j * LANES];
+            part[2 * k] = fmaf(z, wa[j], part[2 * k]);
+            part[2 * k + 1] = fmaf(z, wb[j], part[2 * k + 1]);
+          }
       }
     }
 #pragma unroll
@@ -278,12 +288,16 @@ __global__ __launch_bounds__(256) void si_combine_kernel(const float *scratch, i
 }  // namespace
 
 // blocks of S filtered samples one NT-point transform yields for supports of M taps (0: none)
+constexpr int kMaxWindowRegs = 16;
 static int blocks_for(int NT, int M, int S) {
   if (M > NT) return 0;
   const int blocks = std::min(kMaxBlocks, (NT - (M - 1)) / S);
-  // the transposition area(s) of the transform are reused for its 2 V + 1 weighted samples
+  const int lanes = NT / kL;  // of one transform
+  if (blocks < 1 || S > kMaxWindowRegs * lanes) return 0;
+  // the transposition area(s) of the transform are reused for its V squared samples; the block sums
+  // read up to kMaxWindowRegs * lanes samples from a block's start (weighted away past its end)
   const size_t area = (size_t)(NT / kN) * kL * kRowStride * sizeof(float2);
-  return (blocks >= 1 && ((size_t)2 * blocks * S + 1) * sizeof(float) <= area) ? blocks : 0;
+  return ((size_t)(blocks - 1) * S + (size_t)kMaxWindowRegs * lanes + 1) * sizeof(float) <= area ? blocks : 0;
 }
 
 int32_t si_fft_tables_create(pds_si_plan *plan, const double *taps) {
@@ -373,9 +387,11 @@ int32_t launch_si_fft(const pds_si_plan *plan, const float *d_signal, const int6
   p.C = d.num_coeffs;
   p.blocks = plan->fft.blocks;
   p.use_power = d.use_power;
-  const size_t smem = ((size_t)2 * kWaves * kL * kRowStride) * sizeof(float2) +
-                      (size_t)2 * p.blocks * p.S * sizeof(float);
-  auto kern = plan->fft.big ? si_fft_kernel<true> : si_fft_kernel<false>;
+  const size_t smem = ((size_t)2 * kWaves * kL * kRowStride + (plan->fft.big ? 2 : 1) * kL * kL) * sizeof(float2);
+  const int lanes = plan->fft.big ? 64 : kL;
+  const bool few = p.S <= 8 * lanes;  // window factors per lane and half: 8 or kMaxWindowRegs
+  auto kern = plan->fft.big ? (few ? si_fft_kernel<true, 8> : si_fft_kernel<true, kMaxWindowRegs>)
+                            : (few ? si_fft_kernel<false, 8> : si_fft_kernel<false, kMaxWindowRegs>);
   const int per_wg = plan->fft.big ? kWaves : 2 * kWaves;  // transforms per workgroup
   PDS_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
   dim3 grid((unsigned)((transforms + per_wg - 1) / per_wg), (unsigned)B);
