@@ -108,6 +108,10 @@ __global__ __launch_bounds__(kWaves * 64, 1) void si_fft_kernel(const SiFftArgs 
   float2 *xch_all = reinterpret_cast<float2 *>(si_fft_smem);          // [2 kWaves][32][33]
   float2 *tw = xch_all + 2 * kWaves * kL * kRowStride;                // [32][32]
   float2 *tw2 = tw + kL * kL;                                         // [32][32] (BIG)
+  // (the padding slots of the exchange rows are never written and the block sums may read them,
+  // weighted by zero: they must not hold a NaN another kernel left behind)
+  for (int i = threadIdx.x; i < kWaves * kL * kRowStride; i += kWaves * 64)
+    reinterpret_cast<float4 *>(xch_all)[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
   for (int i = threadIdx.x; i < kL * kL; i += kWaves * 64) {
     tw[i] = p.twiddle[i];
     if constexpr (BIG) tw2[i] = p.twiddle2k[i];
@@ -171,10 +175,11 @@ __global__ __launch_bounds__(kWaves * 64, 1) void si_fft_kernel(const SiFftArgs 
     xr[q] = zr[q];
     xi[q] = zi[q];
   }
-  // |y|^2 of the V filtered samples (+ one dump slot) after the last transposition of a filter
-  // (2048-point form: the wave's two areas, contiguous)
+  // |y|^2 of the transform's NT samples after the last transposition of a filter (2048-point form:
+  // the wave's two areas, contiguous); the lane writes its samples and reads its share of the blocks
   float *zw = reinterpret_cast<float *>(BIG ? xch_all + (half & ~1) * kL * kRowStride : xch);
-  const float *zl = zw + lt;
+  float *zw_l = zw + (BIG ? 2 * l + hw : l);
+  const float *zl = zw + first_valid + lt;
   float *srow = p.scratch + ((int64_t)b * p.blocks_per_utt + d * p.blocks) * p.C * 2;
   // the filter's spectrum is fetched while the block sums of the filter before are formed: by then
   // the transform's registers are free, and the loads land under the sums
@@ -207,14 +212,21 @@ __global__ __launch_bounds__(kWaves * 64, 1) void si_fft_kernel(const SiFftArgs 
     }
     fft1024(zr, zi, xch, tw, l);
     PDS_SI_PHASE();
-    // |y|^2 (the conjugation does not matter) -> LDS; samples before the alias-free part go to a
-    // dump slot behind the array (no branches in this loop)
+    // |y|^2 (the conjugation does not matter) -> LDS, at the sample's own position in the transform
+    // (one address register, the row in the instruction's offset); groups of four rows that lie
+    // wholly inside the aliased part are skipped by a scalar branch
 #pragma unroll
-    for (int q = 0; q < kL; ++q) {
-      const int m = sample_of(q) - first_valid;  // position inside the V filtered samples
-      float z = zr[q] * zr[q] + zi[q] * zi[q];
-      if (!p.use_power) z = __builtin_amdgcn_sqrtf(z);
-      zw[m >= 0 ? m : V] = z;
+    for (int q4 = 0; q4 < kL; q4 += 4) {
+      if (LANES * (q4 + 4) <= first_valid) continue;
+      float z[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) z[i] = zr[q4 + i] * zr[q4 + i] + zi[q4 + i] * zi[q4 + i];
+      if (!p.use_power) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) z[i] = __builtin_amdgcn_sqrtf(z[i]);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) zw_l[LANES * (q4 + i)] = z[i];
     }
     half_wave_sync();
     PDS_SI_PHASE();
@@ -237,33 +249,37 @@ __global__ __launch_bounds__(kWaves * 64, 1) void si_fft_kernel(const SiFftArgs 
       part[2 * k + 1] = 0.0f;
       if (k < p.blocks) {
         const float *src = zl + k * p.S;
+        float zs[NW];
 #pragma unroll
-        for (int j = 0; j < NW; ++j)
-          if (j * LANES < p.S) {
-            const float z = src[j * LANES];
-            part[2 * k] = fmaf(z, wa[j], part[2 * k]);
-            part[2 * k + 1] = fmaf(z, wb[j], part[2 * k + 1]);
-          }
+        for (int j = 0; j < NW; ++j) zs[j] = src[j * LANES];
+#pragma unroll
+        for (int j = 0; j < NW; ++j) {
+          part[2 * k] = fmaf(zs[j], wa[j], part[2 * k]);
+          part[2 * k + 1] = fmaf(zs[j], wb[j], part[2 * k + 1]);
+        }
       }
     }
 #pragma unroll
-    for (int task = 0; task < 2 * kMaxBlocks; ++task) {
-      float v = part[task];
-      v = dpp_sum<0xB1>(v);   // quad_perm [1,0,3,2]
-      v = dpp_sum<0x4E>(v);   // quad_perm [2,3,0,1]
-      v = dpp_sum<0x141>(v);  // row_half_mirror
-      v = dpp_sum<0x140>(v);  // row_mirror
-      part[task] = v;
-    }
+    for (int k = 0; k < kMaxBlocks; ++k)
+      if (k < p.blocks) {
 #pragma unroll
-    for (int task = 0; task < 2 * kMaxBlocks; ++task) {
-      part[task] += __shfl_xor(part[task], 16, 64);
-      if constexpr (BIG) part[task] += __shfl_xor(part[task], 32, 64);
-    }
+        for (int task = 2 * k; task < 2 * k + 2; ++task) {
+          float v = part[task];
+          v = dpp_sum<0xB1>(v);   // quad_perm [1,0,3,2]
+          v = dpp_sum<0x4E>(v);   // quad_perm [2,3,0,1]
+          v = dpp_sum<0x141>(v);  // row_half_mirror
+          v = dpp_sum<0x140>(v);  // row_mirror
+          v += __shfl_xor(v, 16, 64);
+          if constexpr (BIG) v += __shfl_xor(v, 32, 64);
+          part[task] = v;
+        }
+      }
+    if (lt == 0 && has_work) {
 #pragma unroll
-    for (int task = 0; task < 2 * kMaxBlocks; ++task)
-      if (task < 2 * p.blocks && lt == 0 && has_work)
-        srow[((int64_t)(task >> 1) * p.C + c) * 2 + (task & 1)] = part[task];
+      for (int task = 0; task < 2 * kMaxBlocks; ++task)
+        if (task < 2 * p.blocks)
+          srow[((int64_t)(task >> 1) * p.C + c) * 2 + (task & 1)] = part[task];
+    }
     half_wave_sync();
   }
 }
@@ -294,10 +310,9 @@ static int blocks_for(int NT, int M, int S) {
   const int blocks = std::min(kMaxBlocks, (NT - (M - 1)) / S);
   const int lanes = NT / kL;  // of one transform
   if (blocks < 1 || S > kMaxWindowRegs * lanes) return 0;
-  // the transposition area(s) of the transform are reused for its V squared samples; the block sums
-  // read up to kMaxWindowRegs * lanes samples from a block's start (weighted away past its end)
-  const size_t area = (size_t)(NT / kN) * kL * kRowStride * sizeof(float2);
-  return ((size_t)(blocks - 1) * S + (size_t)kMaxWindowRegs * lanes + 1) * sizeof(float) <= area ? blocks : 0;
+  // (the transposition area(s) of the transform -- 2.06 NT floats -- are reused for its NT squared
+  // samples; the block sums read less than `lanes` floats past them, weighted by zero)
+  return blocks;
 }
 
 int32_t si_fft_tables_create(pds_si_plan *plan, const double *taps) {
@@ -389,9 +404,13 @@ int32_t launch_si_fft(const pds_si_plan *plan, const float *d_signal, const int6
   p.use_power = d.use_power;
   const size_t smem = ((size_t)2 * kWaves * kL * kRowStride + (plan->fft.big ? 2 : 1) * kL * kL) * sizeof(float2);
   const int lanes = plan->fft.big ? 64 : kL;
-  const bool few = p.S <= 8 * lanes;  // window factors per lane and half: 8 or kMaxWindowRegs
-  auto kern = plan->fft.big ? (few ? si_fft_kernel<true, 8> : si_fft_kernel<true, kMaxWindowRegs>)
-                            : (few ? si_fft_kernel<false, 8> : si_fft_kernel<false, kMaxWindowRegs>);
+  // window factors per lane and half: the smallest of the built counts that covers a block
+  const int nw = (p.S + lanes - 1) / lanes;
+  void (*kern)(const SiFftArgs);
+  if (plan->fft.big)
+    kern = nw <= 3 ? si_fft_kernel<true, 3> : nw <= 5 ? si_fft_kernel<true, 5> : nw <= 8 ? si_fft_kernel<true, 8> : si_fft_kernel<true, kMaxWindowRegs>;
+  else
+    kern = nw <= 3 ? si_fft_kernel<false, 3> : nw <= 5 ? si_fft_kernel<false, 5> : nw <= 8 ? si_fft_kernel<false, 8> : si_fft_kernel<false, kMaxWindowRegs>;
   const int per_wg = plan->fft.big ? kWaves : 2 * kWaves;  // transforms per workgroup
   PDS_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
   dim3 grid((unsigned)((transforms + per_wg - 1) / per_wg), (unsigned)B);
