@@ -29,6 +29,9 @@
 // the block sums of one filter with the spectrum product of the next, and the kernel is 7 % slower
 // (1024-point form, si_gabor40; the 2048-point form does not care).
 #define PDS_SI_PHASE() __builtin_amdgcn_sched_barrier(0)
+#ifndef PDS_SI_TW_BATCH
+#define PDS_SI_TW_BATCH 16
+#endif
 
 namespace pds {
 
@@ -37,6 +40,7 @@ namespace {
 constexpr int kN = 1024, kL = 32;       // transform size; lanes = registers = 32
 constexpr int kRowStride = kL + 1;      // exchange row stride in float2: conflict-free both ways
 constexpr int kWaves = 8;               // wavefronts per workgroup (two per SIMD), two transforms each
+constexpr int kTwBatch = PDS_SI_TW_BATCH;   // twiddle rows read from LDS at a time
 constexpr int kMaxBlocks = 8;           // shift-sized blocks a transform may yield (register budget)
 
 // x + (x of the lane a DPP control word selects inside the 16-lane row)
@@ -69,13 +73,25 @@ __device__ __forceinline__ void half_wave_sync() {
 __device__ __forceinline__ void fft1024(float (&zr)[kL], float (&zi)[kL], float2 *xch, const float2 *tw, int l) {
   float ar[kL], ai[kL];
   inl::CFFT<kL, 1>::run(zr, zi, ar, ai);
+  // (twiddles in batches of kTwBatch rows: a table read behind an exchange write waits for it, one round
+  // trip per row if they alternate)
 #pragma unroll
-  for (int q = 0; q < kL; ++q) {
-    const float2 t = tw[q * kL + l];
-    float2 v;
-    v.x = ar[q] * t.x - ai[q] * t.y;
-    v.y = ar[q] * t.y + ai[q] * t.x;
-    xch[q * kRowStride + l] = v;
+  for (int q0 = 0; q0 < kL; q0 += kTwBatch) {
+    float tr[kTwBatch], ti[kTwBatch];
+#pragma unroll
+    for (int i = 0; i < kTwBatch; ++i) {
+      const float2 t = tw[(q0 + i) * kL + l];
+      tr[i] = t.x;
+      ti[i] = t.y;
+    }
+#pragma unroll
+    for (int i = 0; i < kTwBatch; ++i) {
+      const int q = q0 + i;
+      float2 v;
+      v.x = ar[q] * tr[i] - ai[q] * ti[i];
+      v.y = ar[q] * ti[i] + ai[q] * tr[i];
+      xch[q * kRowStride + l] = v;
+    }
   }
   half_wave_sync();
 #pragma unroll
@@ -190,6 +206,18 @@ __global__ __launch_bounds__(kWaves * 64, 1) void si_fft_kernel(const SiFftArgs 
     hr[q] = hs.x;
     hi[q] = hs.y;
   }
+  // a filter's sums are stored one pass later, in front of the next spectrum's loads: the wait for
+  // those loads at the top of a pass then does not wait for stores issued behind them
+  float tot[kMaxBlocks];
+  const bool storer = has_work && lt < 32 && (lt & 15) == 0;
+  float *sdst = srow + (lt >> 4);
+  auto store_sums = [&](int c) {
+    if (storer) {
+#pragma unroll
+      for (int k = 0; k < kMaxBlocks; ++k)
+        if (k < p.blocks) sdst[((int64_t)k * p.C + c) * 2] = tot[k];
+    }
+  };
   for (int c = 0; c < p.C; ++c) {
     PDS_SI_PHASE();
     // conj(X H): the inverse transform is conj(FFT(conj(.))) (1 / 1024 is folded into H)
@@ -230,6 +258,7 @@ __global__ __launch_bounds__(kWaves * 64, 1) void si_fft_kernel(const SiFftArgs 
     }
     half_wave_sync();
     PDS_SI_PHASE();
+    if (c > 0) store_sums(c - 1);
     {
       const float2 *h = p.spectra + (size_t)(c + 1 < p.C ? c + 1 : c) * NT;
 #pragma unroll
@@ -240,48 +269,41 @@ __global__ __launch_bounds__(kWaves * 64, 1) void si_fft_kernel(const SiFftArgs 
       }
     }
     // every lane weights its share of every block with the two window halves (independent LDS
-    // reads), then the butterflies of all 2 * blocks sums run side by side: four DPP steps inside
-    // the 16-lane rows and one exchange between the two rows of the half-wave
-    float part[2 * kMaxBlocks];
+    // reads); four DPP steps sum inside the 16-lane rows, and one row swap between a block's two sums
+    // leaves the first-half sum in the transform's lane 0 and the second-half sum in its lane 16
 #pragma unroll
-    for (int k = 0; k < kMaxBlocks; ++k) {
-      part[2 * k] = 0.0f;
-      part[2 * k + 1] = 0.0f;
+    for (int k = 0; k < kMaxBlocks; ++k)
       if (k < p.blocks) {
         const float *src = zl + k * p.S;
         float zs[NW];
 #pragma unroll
         for (int j = 0; j < NW; ++j) zs[j] = src[j * LANES];
+        float va = 0.0f, vb = 0.0f;
 #pragma unroll
         for (int j = 0; j < NW; ++j) {
-          part[2 * k] = fmaf(zs[j], wa[j], part[2 * k]);
-          part[2 * k + 1] = fmaf(zs[j], wb[j], part[2 * k + 1]);
+          va = fmaf(zs[j], wa[j], va);
+          vb = fmaf(zs[j], wb[j], vb);
         }
-      }
-    }
-#pragma unroll
-    for (int k = 0; k < kMaxBlocks; ++k)
-      if (k < p.blocks) {
-#pragma unroll
-        for (int task = 2 * k; task < 2 * k + 2; ++task) {
-          float v = part[task];
-          v = dpp_sum<0xB1>(v);   // quad_perm [1,0,3,2]
-          v = dpp_sum<0x4E>(v);   // quad_perm [2,3,0,1]
-          v = dpp_sum<0x141>(v);  // row_half_mirror
-          v = dpp_sum<0x140>(v);  // row_mirror
-          v += __shfl_xor(v, 16, 64);
-          if constexpr (BIG) v += __shfl_xor(v, 32, 64);
-          part[task] = v;
+        va = dpp_sum<0xB1>(va);   // quad_perm [1,0,3,2]
+        vb = dpp_sum<0xB1>(vb);
+        va = dpp_sum<0x4E>(va);   // quad_perm [2,3,0,1]
+        vb = dpp_sum<0x4E>(vb);
+        va = dpp_sum<0x141>(va);  // row_half_mirror
+        vb = dpp_sum<0x141>(vb);
+        va = dpp_sum<0x140>(va);  // row_mirror
+        vb = dpp_sum<0x140>(vb);
+        // rows (a0 b0 a2 b2) + (a1 b1 a3 b3)
+        const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(va), __float_as_uint(vb), false, false);
+        float r = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+        if constexpr (BIG) {
+          const auto s2 = __builtin_amdgcn_permlane32_swap(__float_as_uint(r), __float_as_uint(r), false, false);
+          r = __uint_as_float(s2[0]) + __uint_as_float(s2[1]);
         }
+        tot[k] = r;
       }
-    if (lt == 0 && has_work) {
-#pragma unroll
-      for (int task = 0; task < 2 * kMaxBlocks; ++task)
-        if (task < 2 * p.blocks)
-          srow[((int64_t)(task >> 1) * p.C + c) * 2 + (task & 1)] = part[task];
-    }
     half_wave_sync();
   }
+  store_sums(p.C - 1);
 }
 
 // frame t = first-half sum of block t + second-half sum of block t + 1 (compute.py:980-990)
