@@ -61,6 +61,12 @@ struct SiFftArgs {
   int S, C, blocks, use_power;
 };
 
+// lower half-wave: x(lane) + x(lane + 32); upper half-wave: x(lane - 32) - x(lane)  (sgn = +1 / -1)
+__device__ __forceinline__ float halves_sum(float x, float sgn) {
+  const auto s = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  return fmaf(sgn, __uint_as_float(s[1]), __uint_as_float(s[0]));
+}
+
 __device__ __forceinline__ void half_wave_sync() {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
@@ -123,15 +129,15 @@ __global__ __launch_bounds__(kWaves * 64, 1) void si_fft_kernel(const SiFftArgs 
   extern __shared__ __attribute__((aligned(16))) unsigned char si_fft_smem[];
   float2 *xch_all = reinterpret_cast<float2 *>(si_fft_smem);          // [2 kWaves][32][33]
   float2 *tw = xch_all + 2 * kWaves * kL * kRowStride;                // [32][32]
-  float2 *tw2 = tw + kL * kL;                                         // [32][32] (BIG)
+  float2 *tw2 = tw + kL * kL;  // [32][64] (BIG): row q = 32 x (1, 0) for the lower half-wave, W_2048^(32 q + l) for the upper
   // (the padding slots of the exchange rows are never written and the block sums may read them,
   // weighted by zero: they must not hold a NaN another kernel left behind)
   for (int i = threadIdx.x; i < kWaves * kL * kRowStride; i += kWaves * 64)
     reinterpret_cast<float4 *>(xch_all)[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-  for (int i = threadIdx.x; i < kL * kL; i += kWaves * 64) {
-    tw[i] = p.twiddle[i];
-    if constexpr (BIG) tw2[i] = p.twiddle2k[i];
-  }
+  for (int i = threadIdx.x; i < kL * kL; i += kWaves * 64) tw[i] = p.twiddle[i];
+  if constexpr (BIG)
+    for (int i = threadIdx.x; i < 2 * kL * kL; i += kWaves * 64)
+      tw2[i] = (i & 32) ? p.twiddle2k[(i >> 6) * kL + (i & 31)] : make_float2(1.0f, 0.0f);
   __syncthreads();
   const int half = threadIdx.x >> 5;       // 0 .. 2 kWaves - 1: one FFT-1024 each
   const int l = threadIdx.x & 31;
@@ -165,6 +171,7 @@ __global__ __launch_bounds__(kWaves * 64, 1) void si_fft_kernel(const SiFftArgs 
     wa[j] = m < p.S ? p.window[m] : 0.0f;
     wb[j] = m < p.S ? p.window[p.S + m] : 0.0f;
   }
+  const float sgn = hw ? -1.0f : 1.0f;
   float zr[kL], zi[kL];
 #pragma unroll
   for (int q = 0; q < kL; ++q) {
@@ -174,15 +181,14 @@ __global__ __launch_bounds__(kWaves * 64, 1) void si_fft_kernel(const SiFftArgs 
   }
   fft1024(zr, zi, xch, tw, l);
   if constexpr (BIG) {
-    // X[j] = E[j] + W^j O[j] (lower half), X[j + 1024] = E[j] - W^j O[j] (upper half)
+    // X[j] = E[j] + W^j O[j] (lower half), X[j + 1024] = E[j] - W^j O[j] (upper half): the upper half
+    // multiplies (the lower one by 1), v_permlane32_swap hands every lane both halves' values
 #pragma unroll
     for (int q = 0; q < kL; ++q) {
-      const float2 t2 = tw2[q * kL + l];
-      const float ur = hw ? zr[q] * t2.x - zi[q] * t2.y : zr[q];
-      const float ui = hw ? zr[q] * t2.y + zi[q] * t2.x : zi[q];
-      const float pr = __shfl_xor(ur, 32, 64), pi = __shfl_xor(ui, 32, 64);
-      zr[q] = hw ? pr - ur : ur + pr;
-      zi[q] = hw ? pi - ui : ui + pi;
+      const float2 t2 = tw2[q * 64 + lt];
+      const float ur = zr[q] * t2.x - zi[q] * t2.y, ui = zr[q] * t2.y + zi[q] * t2.x;
+      zr[q] = halves_sum(ur, sgn);
+      zi[q] = halves_sum(ui, sgn);
     }
   }
   float xr[kL], xi[kL];  // the stretch's spectrum stays in the lane's registers for every filter
@@ -230,12 +236,17 @@ __global__ __launch_bounds__(kWaves * 64, 1) void si_fft_kernel(const SiFftArgs 
     if constexpr (BIG) {
       // a[j] = Z[j] + Z[j + 1024] (lower half), b[j] = (Z[j] - Z[j + 1024]) W^j (upper half)
 #pragma unroll
-      for (int q = 0; q < kL; ++q) {
-        const float2 t2 = tw2[q * kL + l];
-        const float pr = __shfl_xor(zr[q], 32, 64), pi = __shfl_xor(zi[q], 32, 64);
-        const float dr = pr - zr[q], di = pi - zi[q];
-        zr[q] = hw ? dr * t2.x - di * t2.y : zr[q] + pr;
-        zi[q] = hw ? dr * t2.y + di * t2.x : zi[q] + pi;
+      for (int q0 = 0; q0 < kL; q0 += kTwBatch) {
+        float2 t2[kTwBatch];
+#pragma unroll
+        for (int i = 0; i < kTwBatch; ++i) t2[i] = tw2[(q0 + i) * 64 + lt];
+#pragma unroll
+        for (int i = 0; i < kTwBatch; ++i) {
+          const int q = q0 + i;
+          const float sr = halves_sum(zr[q], sgn), si = halves_sum(zi[q], sgn);
+          zr[q] = sr * t2[i].x - si * t2[i].y;
+          zi[q] = sr * t2[i].y + si * t2[i].x;
+        }
       }
     }
     fft1024(zr, zi, xch, tw, l);
@@ -424,7 +435,7 @@ int32_t launch_si_fft(const pds_si_plan *plan, const float *d_signal, const int6
   p.C = d.num_coeffs;
   p.blocks = plan->fft.blocks;
   p.use_power = d.use_power;
-  const size_t smem = ((size_t)2 * kWaves * kL * kRowStride + (plan->fft.big ? 2 : 1) * kL * kL) * sizeof(float2);
+  const size_t smem = ((size_t)2 * kWaves * kL * kRowStride + (plan->fft.big ? 3 : 1) * kL * kL) * sizeof(float2);
   const int lanes = plan->fft.big ? 64 : kL;
   // window factors per lane and half: the smallest of the built counts that covers a block
   const int nw = (p.S + lanes - 1) / lanes;
