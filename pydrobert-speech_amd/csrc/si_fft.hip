@@ -28,7 +28,11 @@
 // Phase boundaries of a filter's pass, as scheduling barriers: left alone, the compiler interleaves
 // the block sums of one filter with the spectrum product of the next, and the kernel is 7 % slower
 // (1024-point form, si_gabor40; the 2048-point form does not care).
+#ifdef PDS_SI_NO_PHASE
+#define PDS_SI_PHASE()
+#else
 #define PDS_SI_PHASE() __builtin_amdgcn_sched_barrier(0)
+#endif
 #ifndef PDS_SI_TW_BATCH
 #define PDS_SI_TW_BATCH 16
 #endif

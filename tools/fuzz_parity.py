@@ -142,9 +142,10 @@ def main():
 
     count = int(sys.argv[1]) if len(sys.argv) > 1 else 100
     rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+    si_only = len(sys.argv) > 3 and sys.argv[3] == "si"  # short-integration computers only
     fails, kinds = 0, {}
     for i in range(count):
-        cfg = draw_si(rng) if i % 10 == 9 else draw_stft(rng)
+        cfg = draw_si(rng) if (i % 10 == 9 or si_only) else draw_stft(rng)
         try:
             comp = alias_factory_subclass_from_arg(ps.compute.FrameComputer, json.loads(json.dumps(cfg)))
         except Exception as exc:  # invalid draws (e.g. filters above Nyquist) are not failures
