@@ -151,3 +151,9 @@ extern unsigned long long *g_stamp_buf;  // (stft_fast.hip: pds_debug_set_stamp_
 #define PDS_PF_ILV 0
 #endif
 }  // namespace pds
+
+// Mirror-image bins of the power spectrum stored from their lowest address up (one address register + immediate
+// offsets) instead of counted down from N - k (one hoisted address register per step).
+#ifndef PDS_MIRROR_REBASE
+#define PDS_MIRROR_REBASE 1
+#endif

@@ -1462,11 +1462,14 @@ __global__ __launch_bounds__(MAXWAVES * 64, MINW) void stft_wave_kernel(const Fa
     constexpr int PDUMP = RSG ? NBP : PSTR - 1;       // bin index of the padding slot
     if constexpr (PSPLIT) {
       // the lane's bins: pc + N1 k2 for k2 = k + PQ h, and the mirror images N - pc - N1 (k2 + PH)
+      // (the mirror images from their LOWEST address up: one address register and the step in the instruction's
+      // offset; counted down from hi_bin the compiler kept an address per step, sixteen registers it had to spill)
       const int lo_bin = pc + N1 * PQ * ph, hi_bin = N / 2 - pc - N1 * PQ * ph;
+      float *const Plo = Pw + lo_bin * PB, *const Phi = Pw + (hi_bin - N1 * (PQ - 1)) * PB;
 #pragma unroll
       for (int k = 0; k < PQ; ++k) {
-        Pw[(lo_bin + N1 * k) * PB] = pw[0][k];
-        Pw[(hi_bin - N1 * k) * PB] = pw[0][PQ + k];
+        Plo[N1 * k * PB] = pw[0][k];
+        Phi[N1 * (PQ - 1 - k) * PB] = pw[0][PQ + k];
       }
     } else
 #pragma unroll
@@ -1481,6 +1484,16 @@ __global__ __launch_bounds__(MAXWAVES * 64, MINW) void stft_wave_kernel(const Fa
         // the special bins written next overwrite).  Lanes beyond the last column (only when the
         // columns do not fill the lanes) send theirs to the padding slot.
         const bool live = G::FULL || kk < COLS;
+        if constexpr (G::FULL && PDS_MIRROR_REBASE) {
+          // bins kk + N1 k2 up to N/2, then the mirror images N - kk - N1 k2 -- written from their LOWEST
+          // address up, so that both runs are one address register + the step in the instruction's offset
+          // (counted down, the compiler keeps one address per step: N2/2 registers)
+          float *const Pa = Pw + kk * PB, *const Pm = Pw + (N1 - kk) * PB;
+#pragma unroll
+          for (int k2 = 0; k2 < N2 / 2; ++k2) Pa[N1 * k2 * PB] = pw[q][k2];
+#pragma unroll
+          for (int k2 = N2 / 2; k2 < N2; ++k2) Pm[N1 * (N2 - 1 - k2) * PB] = pw[q][k2];
+        } else
 #pragma unroll
         for (int k2 = 0; k2 < N2; ++k2) {
           // bin kk + N1*k2, or its mirror image when beyond N/2
