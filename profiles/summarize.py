@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Condense a profiles/run_profile.sh output directory into one text summary.
 
-    python profiles/summarize.py gpurun_out/prof_<tag> [frames_per_launch] > profiles/<tag>_summary.txt
+    python profiles/summarize.py gpurun_out/prof_<tag> [frames_per_launch [timed_steps [kernel-name substring]]] > profiles/<tag>_summary.txt
 """
 import collections
 import csv
@@ -17,14 +17,15 @@ lines.append("rocprofv3 --kernel-trace --stats (top kernels)")
 for r in stats[:4]:
     lines.append("  %-70s calls %s avg_ns %s min_ns %s max_ns %s pct %s" % (
         r["Name"][:70], r["Calls"], r["AverageNs"], r["MinNs"], r["MaxNs"], r["Percentage"]))
-kern = next(r for r in stats if "stft_" in r["Name"])
-avg_s = float(kern["AverageNs"]) * 1e-9
 # bench.py times its LAST `steps` launches (after the clock pre-roll and the warm-up): the same
 # window from the kernel trace is the duration its roofline line must agree with
 steps = int(sys.argv[3]) if len(sys.argv) > 3 else 100
+KERN = sys.argv[4] if len(sys.argv) > 4 else "stft_"  # the kernel the summary is about
+kern = next(r for r in stats if KERN in r["Name"])
+avg_s = float(kern["AverageNs"]) * 1e-9
 trace_path = os.path.join(d, "stats", "stats_kernel_trace.csv")
 if os.path.exists(trace_path):
-    rows = [r for r in csv.DictReader(open(trace_path)) if "stft_" in r["Kernel_Name"]]
+    rows = [r for r in csv.DictReader(open(trace_path)) if KERN in r["Kernel_Name"]]
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
     last = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in rows[-steps:]]
     first = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in rows[:40]]
@@ -39,7 +40,7 @@ for sub in ("pmc_fetch", "pmc_write", "pmc_sq1", "pmc_sq2", "pmc_misc"):
     agg = collections.defaultdict(list)
     meta = None
     for r in csv.DictReader(open(path)):
-        if "stft_" in r["Kernel_Name"]:
+        if KERN in r["Kernel_Name"]:
             agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
             meta = r
     for k, v in agg.items():
@@ -47,7 +48,7 @@ for sub in ("pmc_fetch", "pmc_write", "pmc_sq1", "pmc_sq2", "pmc_misc"):
 if meta:
     lines.append("dispatch: grid %s wg %s VGPR %s SGPR %s LDS_static %s" % (
         meta["Grid_Size"], meta["Workgroup_Size"], meta["VGPR_Count"], meta["SGPR_Count"], meta["LDS_Block_Size"]))
-lines.append("PMC means per launch of the STFT kernel (separate passes):")
+lines.append("PMC means per launch of the %s kernel (separate passes):" % KERN)
 for k in sorted(tot):
     lines.append("  %-24s %.6g" % (k, tot[k]))
 it = frames / 4.0
