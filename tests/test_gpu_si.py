@@ -175,3 +175,40 @@ def test_streaming_random_chunkings_call_by_call(name):
         outs = [comp.compute_chunk(p) for p in np.split(x, g[f"{name}/{case}/cuts"])] + [comp.finalize()]
         assert [len(o) for o in outs] == g[f"{name}/{case}/counts"].tolist(), (name, case)
         close(np.concatenate(outs), g[f"{name}/{case}/feats"], **F32)
+
+
+@pytest.mark.parametrize("rate,shift_ms,bank,num_filts,use_power,size", [
+    (8000, 5, "gabor", 5, True, 1024),         # S = 40: <= 3 window factors per lane and half
+    (16000, 10, "gabor", 5, False, 1024),      # S = 160: 5 factors; magnitudes (the square-root branch)
+    (16000, 15, "gabor", 5, True, 1024),       # S = 240: 8 factors
+    (16000, 25, "gabor", 5, True, 1024),       # S = 400: 16 factors
+    (48000, 2.5, "gammatone", 40, True, 2048),  # S = 120, 754 taps: 2048-point form (64 lanes), 3 factors
+    (48000, 5, "gammatone", 5, True, 2048),    # S = 240: 5 factors
+    (48000, 10, "gabor", 5, False, 2048),      # S = 480: 8 factors
+    (48000, 16, "gabor", 5, True, 2048),       # S = 768: 16 factors
+])
+def test_fft_form_window_factor_buckets_against_oracle(rate, shift_ms, bank, num_filts, use_power, size):
+    """csrc/si_fft.hip keeps ceil(S / lanes) window factors per lane in registers, built for 3 / 5 / 8 / 16 of them,
+    for 32 (1024-point transforms) or 64 lanes (2048-point): every instantiation against the oracle, the direct form
+    beside it, with lengths that leave partial transforms and partial blocks"""
+    import torch
+
+    comp = alias_factory_subclass_from_arg(
+        FrameComputer, {"name": "si", "bank": {"name": bank, "scaling_function": "mel", "num_filts": num_filts,
+                                               "sampling_rate": rate},
+                        "frame_shift_ms": shift_ms, "use_power": use_power, "use_log": use_power})
+    assert comp.fft_size == size, (comp.fft_size, comp._max_support, comp.frame_shift)
+    p = so.SiParams(comp.frame_shift, comp._max_support, comp._translation, comp.dft_size, comp.taps,
+                    comp._window.reshape(-1), comp.frame_style == "centered", use_power, use_power)
+    rng = np.random.default_rng(int(rate + 10 * shift_ms))
+    S = comp.frame_shift
+    lens = [0, 1, S - 1, 3 * S + 7, 41 * S + S // 2, 9000]
+    sigs = [(1000 * rng.standard_normal(n)).astype("f4") for n in lens]
+    got = comp.compute_full_batch(sigs)
+    for x, y in zip(sigs, got):
+        close(y, so.compute_full(x, p), **F32)
+    x = torch.from_numpy(np.concatenate(sigs)).cuda()
+    offs = np.concatenate([[0], np.cumsum(lens)[:-1]])
+    fft, rows = comp.compute_packed(x, offs, lens)
+    direct, _ = comp.compute_packed(x, offs, lens, direct=True)
+    close(fft.cpu().numpy(), direct.cpu().numpy(), **F32)
