@@ -9,15 +9,18 @@
 // W_1024^(lane * q), transposition through the half-wave's private LDS area, in-lane FFT again;
 // the result has the same layout (bin k in lane k % 32, register k / 32), so the inverse transform
 // is the same routine between two conjugations, and the spectra of the filters are read in natural
-// order, coalesced.  Per transform block: one forward FFT of the signal stretch (kept in LDS),
-// then per filter a pointwise product, an inverse FFT, |y|^2 times the two window halves into LDS,
-// and one 32-lane butterfly sum per (block, half).  The sums go to a scratch array
-// [utterance][block][coefficient][half]; a second, trivial kernel adds first-half(t) +
-// second-half(t + 1), applies the log and writes the features.  No workgroup barrier after the
-// tables are staged, no atomics; results are bitwise reproducible.
+// order, coalesced.  Per transform block: one forward FFT of the signal stretch (its spectrum stays in
+// the lane's registers), then per filter a pointwise product, an inverse FFT, |y|^2 into LDS at the
+// sample's own position, and per shift-sized block two sums over it weighted by the window's halves
+// (the window repeats from block to block: ceil(S / lanes) factors per lane and half, in registers).
+// The sums go to a scratch array [utterance][block][coefficient][half]; a second, trivial kernel adds
+// first-half(t) + second-half(t + 1), applies the log and writes the features.  No workgroup barrier
+// after the tables are staged, no atomics; results are bitwise reproducible.
 //
-// Cost per filter and transform: ~1.3 k vector instructions per lane for `blocks` frames, against
-// 2 M S per frame for the direct form -- 10x fewer at M = 380, S = 160.
+// Two waves share a SIMD (256 registers each; 8-wave workgroups with 143-160 KB of LDS): the twiddles
+// live in an LDS table, a filter's spectrum is fetched while the sums of the filter before are formed.
+// Cost per filter and transform pair (one wave): ~1.2 k vector instructions for 2 x `blocks` frames,
+// against 2 M S per frame for the direct form.  profiles/HISTORY.md 4.4 has the measurements.
 #include <algorithm>
 #include <cmath>
 #include <vector>
@@ -25,9 +28,8 @@
 #include "fft_inlane.h"
 #include "pds_internal.h"
 
-// Phase boundaries of a filter's pass, as scheduling barriers: left alone, the compiler interleaves
-// the block sums of one filter with the spectrum product of the next, and the kernel is 7 % slower
-// (1024-point form, si_gabor40; the 2048-point form does not care).
+// Phase boundaries of a filter's pass, as scheduling barriers (at one wave per SIMD they were worth 7 %;
+// at two waves -DPDS_SI_NO_PHASE measures +0.5 % on the 1024-point form and -2 % on the 2048-point one).
 #ifdef PDS_SI_NO_PHASE
 #define PDS_SI_PHASE()
 #else
@@ -59,7 +61,7 @@ struct SiFftArgs {
   float *scratch;
   int64_t blocks_per_utt;   // scratch rows (shift-sized blocks) reserved per utterance
   const float2 *spectra, *twiddle;
-  const float2 *twiddle2k;  // [32][32] W_2048^(32 q + l), row q (2048-point form only)
+  const float2 *twiddle2k;  // [32][32] W_2048^(32 q + l), row q (2048-point form only; staged as (1, 0) | W rows)
   const float *window;
   int64_t start;
   int S, C, blocks, use_power;
