@@ -35,6 +35,16 @@
 #else
 #define PDS_SI_PHASE() __builtin_amdgcn_sched_barrier(0)
 #endif
+// Wave priority per phase of a filter's pass (one hex digit each, from the lowest: 0 product + first in-lane
+// transform, 1 twiddles + exchange, 2 second in-lane transform, 3 |y|^2 stores, 4 spectrum loads + block sums);
+// negative: no hints.  The two waves of a SIMD run the same phases: see stft_switches.h on why staggering pays.
+#ifndef PDS_SI_PRIO_1K
+#define PDS_SI_PRIO_1K 0x32110  // 1024-point form: a pass's later phases first
+#endif
+#ifndef PDS_SI_PRIO_2K
+#define PDS_SI_PRIO_2K 0x00012  // 2048-point form: a pass's earlier phases first
+#endif
+#define PDS_SI_SETPRIO(i) do { if (PRIO >= 0) __builtin_amdgcn_s_setprio((PRIO >> (4 * (i))) & 3); } while (0)
 #ifndef PDS_SI_TW_BATCH
 #define PDS_SI_TW_BATCH 16
 #endif
@@ -82,9 +92,11 @@ __device__ __forceinline__ void half_wave_sync() {
 // (zr, zi)[q] = element 32 q + l  ->  (zr, zi)[q] = bin 32 q + l of the 1024-point DFT
 // tw[q * 32 + l] = W_1024^(l q), in LDS: two waves share a SIMD, so a wave has 256 registers and
 // the table's reads are covered by the other wave
+template <int PRIO>
 __device__ __forceinline__ void fft1024(float (&zr)[kL], float (&zi)[kL], float2 *xch, const float2 *tw, int l) {
   float ar[kL], ai[kL];
   inl::CFFT<kL, 1>::run(zr, zi, ar, ai);
+  PDS_SI_SETPRIO(1);
   // (twiddles in batches of kTwBatch rows: a table read behind an exchange write waits for it, one round
   // trip per row if they alternate)
 #pragma unroll
@@ -113,6 +125,7 @@ __device__ __forceinline__ void fft1024(float (&zr)[kL], float (&zi)[kL], float2
     ai[q] = v.y;
   }
   half_wave_sync();
+  PDS_SI_SETPRIO(2);
   inl::CFFT<kL, 1>::run(ar, ai, zr, zi);
 }
 
@@ -132,6 +145,7 @@ template <bool BIG, int NW>
 __global__ __launch_bounds__(kWaves * 64, 1) void si_fft_kernel(const SiFftArgs p) {
   constexpr int NT = BIG ? 2 * kN : kN;
   constexpr int LANES = BIG ? 64 : kL;     // lanes of one transform
+  constexpr int PRIO = BIG ? (PDS_SI_PRIO_2K) : (PDS_SI_PRIO_1K);
   extern __shared__ __attribute__((aligned(16))) unsigned char si_fft_smem[];
   float2 *xch_all = reinterpret_cast<float2 *>(si_fft_smem);          // [2 kWaves][32][33]
   float2 *tw = xch_all + 2 * kWaves * kL * kRowStride;                // [32][32]
@@ -185,7 +199,7 @@ __global__ __launch_bounds__(kWaves * 64, 1) void si_fft_kernel(const SiFftArgs 
     zr[q] = (has_work && idx >= 0 && idx < n) ? x[idx] : 0.0f;
     zi[q] = 0.0f;
   }
-  fft1024(zr, zi, xch, tw, l);
+  fft1024<PRIO>(zr, zi, xch, tw, l);
   if constexpr (BIG) {
     // X[j] = E[j] + W^j O[j] (lower half), X[j + 1024] = E[j] - W^j O[j] (upper half): the upper half
     // multiplies (the lower one by 1), v_permlane32_swap hands every lane both halves' values
@@ -241,6 +255,7 @@ __global__ __launch_bounds__(kWaves * 64, 1) void si_fft_kernel(const SiFftArgs 
   };
   for (int c = 0; c < p.C; ++c) {
     PDS_SI_PHASE();
+    PDS_SI_SETPRIO(0);
     // conj(X H): the inverse transform is conj(FFT(conj(.))) (1 / 1024 is folded into H)
 #pragma unroll
     for (int q = 0; q < kL; ++q) {
@@ -264,8 +279,9 @@ __global__ __launch_bounds__(kWaves * 64, 1) void si_fft_kernel(const SiFftArgs 
         }
       }
     }
-    fft1024(zr, zi, xch, tw, l);
+    fft1024<PRIO>(zr, zi, xch, tw, l);
     PDS_SI_PHASE();
+    PDS_SI_SETPRIO(3);
     // |y|^2 (the conjugation does not matter) -> LDS, at the sample's own position in the transform
     // (one address register, the row in the instruction's offset); groups of four rows that lie
     // wholly inside the aliased part are skipped by a scalar branch
@@ -284,6 +300,7 @@ __global__ __launch_bounds__(kWaves * 64, 1) void si_fft_kernel(const SiFftArgs 
     }
     half_wave_sync();
     PDS_SI_PHASE();
+    PDS_SI_SETPRIO(4);
     if (c > 0) store_sums(c - 1);
     load_spectrum(p.spectra + (size_t)(c + 1 < p.C ? c + 1 : c) * NT);
     // every lane weights its share of every block with the two window halves (independent LDS
