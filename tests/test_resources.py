@@ -83,3 +83,14 @@ def test_instantiation_matrix_stays_bounded():
     assert 0 < len(int16) <= 58 and len(stft) - len(int16) < 232, (len(int16), len(stft))
     worst = max(table.values(), key=lambda k: k.get("vgpr_spill_count", 0))
     assert worst.get("vgpr_spill_count", 0) <= 40, worst
+
+
+def test_short_integration_fft_kernels_fit_two_waves_per_simd_without_scratch():
+    """csrc/si_fft.hip runs two waves per SIMD (256 registers each); its rework of round 3 started from instantiations
+    that spilled 70-110 registers through hoisted per-row addresses -- none may come back"""
+    table, _ = _table()
+    si = {n: k for n, k in table.items() if "si_fft_kernel" in n}
+    assert len(si) == 8, sorted(si)  # {1024-, 2048-point form} x {3, 5, 8, 16 window factors per lane and half}
+    for name, k in si.items():
+        assert k.get("private_segment_fixed_size", 0) == 0 and k.get("vgpr_spill_count", 0) == 0, (name, k)
+        assert k.get("vgpr_count", 0) + k.get("agpr_count", 0) <= 256, (name, k)
