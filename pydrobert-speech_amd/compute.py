@@ -18,6 +18,7 @@ from typing import List, Mapping, Optional, Sequence, Tuple, Union
 import numpy as np
 
 from . import _native, config
+from ._staging import MAX_BYTES as _STAGING_MAX_BYTES, PinnedStaging
 from .alias import AliasedFactory, alias_factory_subclass_from_arg
 from .filters import GammaWindow, HannWindow, LinearFilterBank, WindowFunction
 
@@ -319,6 +320,7 @@ class ShortTimeFourierTransformFrameComputer(LinearFilterBankFrameComputer):
         self._plans = {}  # device index -> _NativePlan (tables live on one GPU)
         self._feeds = {}  # (device index, sample dtype) -> feed.HostFeed of compute_full_batch
         self._feed_lock = threading.Lock()  # a staging ring has one feeding thread: others take the plain path
+        self._staging = PinnedStaging()  # pinned buffers for the batches the ring does not serve (float64 arithmetic)
         self._reset_stream()
 
     # ---- properties ---------------------------------------------------------------
@@ -883,9 +885,26 @@ class ShortTimeFourierTransformFrameComputer(LinearFilterBankFrameComputer):
             through_feed = self._full_batch_through_feed(signals, lengths, in_dtype, preemphasis)
             if through_feed is not None:
                 return through_feed
+            work = np.dtype(self._compute_dtype(in_dtype))
+            nbytes = int(offsets[-1]) * work.itemsize
+            if nbytes > _STAGING_MAX_BYTES and len(signals) > 1:  # (pieces the pinned buffers hold)
+                signals, half = list(signals), len(signals) // 2
+                return (self.compute_full_batch(signals[:half], preemphasis)
+                        + self.compute_full_batch(signals[half:], preemphasis))
+            if self._staging.try_acquire(nbytes):
+                # pinned buffers both ways, the utterances packed by a few threads (_staging.py)
+                try:
+                    packed = self._staging.upload(signals, offsets, work, torch.device("cuda", torch.cuda.current_device()))
+                    feats, rows = self.compute_packed(packed, offsets[:-1], lengths, preemphasis=preemphasis)
+                    feats = self._staging.download(feats)
+                finally:
+                    self._staging.release()
+                if feats.dtype != in_dtype:
+                    feats = feats.astype(in_dtype)
+                return [feats[rows[i] : rows[i + 1]] for i in range(len(signals))]
             host = np.concatenate(
-                [np.asarray(s, dtype=self._compute_dtype(in_dtype)).reshape(-1) for s in signals]
-            ) if offsets[-1] else np.zeros(0, self._compute_dtype(in_dtype))
+                [np.asarray(s, dtype=work).reshape(-1) for s in signals]
+            ) if offsets[-1] else np.zeros(0, work)
             packed = torch.from_numpy(host).to("cuda")
         feats, rows = self.compute_packed(packed, offsets[:-1], lengths, preemphasis=preemphasis)
         if on_gpu:

@@ -18,6 +18,7 @@ from typing import List, Mapping, Optional, Sequence, Union
 import numpy as np
 
 from . import _native, config
+from ._staging import PinnedStaging
 from .alias import alias_factory_subclass_from_arg
 from .compute import _MAX_UTTS_PER_CALL, LinearFilterBankFrameComputer
 from .filters import GammaWindow, HannWindow, LinearFilterBank, WindowFunction
@@ -122,6 +123,7 @@ class ShortIntegrationFrameComputer(LinearFilterBankFrameComputer):
         # samples consumed before integration starts / virtual zeros in front (compute.py:859-865)
         self._skip0, self._lead = (skip, 0) if skip >= 0 else (0, -skip)
         self._plans = {}  # device index -> _SiPlan (tables live on one GPU)
+        self._staging = PinnedStaging()  # pinned buffers of compute_full_batch (allocated on first use)
         self._reset_stream()
 
     # -- properties (compute.py:746-778) ------------------------------------------------------
@@ -303,6 +305,16 @@ class ShortIntegrationFrameComputer(LinearFilterBankFrameComputer):
         work = self._work_dtype(in_dtype)
         lengths = np.asarray([np.asarray(s).size for s in signals], dtype=np.int64)
         offsets = np.concatenate([[0], np.cumsum(lengths)]).astype(np.int64)
+        staging = self._staging
+        if staging.try_acquire(int(offsets[-1]) * work.itemsize):
+            # pinned buffers both ways, the utterances packed by a few threads (_staging.py)
+            try:
+                d_sig = staging.upload(signals, offsets, work, torch.device("cuda", torch.cuda.current_device()))
+                feats, rows = self.compute_packed(d_sig, offsets[:-1], lengths)
+                feats = staging.download(feats).astype(in_dtype, copy=False)
+            finally:
+                staging.release()
+            return [feats[rows[b] : rows[b + 1]] for b in range(len(signals))]
         host = np.zeros(0, work)
         if offsets[-1]:
             host = np.concatenate([np.asarray(s, dtype=work).reshape(-1) for s in signals])

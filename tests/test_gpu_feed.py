@@ -211,3 +211,58 @@ def test_compute_full_from_several_threads_at_once(golden_meta):
         got = list(pool.map(comp.compute_full, sigs * 3))
     for k, g in enumerate(got):
         np.testing.assert_array_equal(g, want[k % len(sigs)])
+
+
+def test_float64_batches_and_short_integration_batches_go_through_pinned_staging(golden_meta, golden_tables, monkeypatch):
+    """_staging.PinnedStaging: the batches the native ring does not serve -- float64 signals in float64 arithmetic,
+    the short-integration computer -- are packed into a pinned buffer by a few threads and come back through one.
+    Same values as one compute_full per signal (itself checked against the reference's fixtures elsewhere) and as
+    the oracle; a batch beyond the buffers' limit is split into pieces; a busy staging falls back to the plain path"""
+    from pydrobert_speech_amd import _staging, compute
+
+    name = "c2_tri_mel40"
+    comp = build(golden_meta["configs"][name])
+    rng = np.random.default_rng(31)
+    lens = [0, 1, 5000, 160000, 33333, 48000, 7]
+    sigs = [3000 * rng.standard_normal(n) for n in lens]  # float64
+    assert sum(lens) * 8 > _staging._MIN_BYTES
+    used = []
+    real_upload = _staging.PinnedStaging.upload
+    monkeypatch.setattr(_staging.PinnedStaging, "upload", lambda self, *a, **k: (used.append(1), real_upload(self, *a, **k))[1])
+    got = comp.compute_full_batch(sigs)
+    assert used, "the batch did not go through the pinned buffers"
+    p = oracle_params(golden_tables, name)
+    for x, y in zip(sigs, got):
+        assert y.dtype == np.float64
+        assert_features_close(y, orc.compute_full(x, p), rtol=1e-9, atol=1e-9, what="float64 batch through pinned staging")
+    # (caller-owned results: the pinned buffer is reused by the next batch)
+    keep = [y.copy() for y in got]
+    comp.compute_full_batch([s[::-1].copy() for s in sigs])
+    for y, k in zip(got, keep):
+        np.testing.assert_array_equal(y, k)
+    # beyond the limit: pieces
+    del used[:]
+    monkeypatch.setattr(compute, "_STAGING_MAX_BYTES", 1 << 20)  # (the batch holds 1.97 MB: halves, quarters ...)
+    pieces = comp.compute_full_batch(sigs)
+    assert len(pieces) == len(sigs) and len(used) >= 1
+    for y, k in zip(pieces, keep):
+        np.testing.assert_array_equal(y, k)
+    # a staging in use by another thread: the plain path, same values
+    del used[:]
+    assert comp._staging.try_acquire(1 << 22)
+    try:
+        plain = comp.compute_full_batch(sigs[:4])
+    finally:
+        comp._staging.release()
+    assert not used
+    for y, k in zip(plain, keep):
+        np.testing.assert_array_equal(y, k)
+    # the short-integration computer
+    si = alias_factory_subclass_from_arg(
+        FrameComputer, {"name": "si", "bank": {"name": "gabor", "scaling_function": "mel", "num_filts": 6}})
+    sigs4 = [(1000 * rng.standard_normal(n)).astype(np.float32) for n in (90000, 0, 12345, 160000, 3)]
+    del used[:]
+    got = si.compute_full_batch(sigs4)
+    assert used
+    for x, y in zip(sigs4, got):
+        np.testing.assert_array_equal(y, si.compute_full(x))
