@@ -75,6 +75,7 @@ struct SiFftArgs {
   const float *window;
   int64_t start;
   int S, C, blocks, use_power;
+  int c_per_group;          // filters a workgroup walks (blockIdx.z picks the group): small batches are split over the filters too
 };
 
 // lower half-wave: x(lane) + x(lane + 32); upper half-wave: x(lane - 32) - x(lane)  (sgn = +1 / -1)
@@ -240,7 +241,8 @@ __global__ __launch_bounds__(kWaves * 64, 1) void si_fft_kernel(const SiFftArgs 
       hi[q] = hs.y;
     }
   };
-  load_spectrum(p.spectra);
+  const int c_lo = blockIdx.z * p.c_per_group, c_hi = min(p.C, c_lo + p.c_per_group);
+  load_spectrum(p.spectra + (size_t)c_lo * NT);
   // a filter's sums are stored one pass later, in front of the next spectrum's loads: the wait for
   // those loads at the top of a pass then does not wait for stores issued behind them
   float tot[kMaxBlocks];
@@ -253,7 +255,7 @@ __global__ __launch_bounds__(kWaves * 64, 1) void si_fft_kernel(const SiFftArgs 
         if (k < p.blocks) sdst[((int64_t)k * p.C + c) * 2] = tot[k];
     }
   };
-  for (int c = 0; c < p.C; ++c) {
+  for (int c = c_lo; c < c_hi; ++c) {
     PDS_SI_PHASE();
     PDS_SI_SETPRIO(0);
     // conj(X H): the inverse transform is conj(FFT(conj(.))) (1 / 1024 is folded into H)
@@ -301,8 +303,8 @@ __global__ __launch_bounds__(kWaves * 64, 1) void si_fft_kernel(const SiFftArgs 
     half_wave_sync();
     PDS_SI_PHASE();
     PDS_SI_SETPRIO(4);
-    if (c > 0) store_sums(c - 1);
-    load_spectrum(p.spectra + (size_t)(c + 1 < p.C ? c + 1 : c) * NT);
+    if (c > c_lo) store_sums(c - 1);
+    load_spectrum(p.spectra + (size_t)(c + 1 < c_hi ? c + 1 : c) * NT);
     // every lane weights its share of every block with the two window halves (independent LDS
     // reads); four DPP steps sum inside the 16-lane rows, and one row swap between a block's two sums
     // leaves the first-half sum in the transform's lane 0 and the second-half sum in its lane 16
@@ -338,7 +340,7 @@ __global__ __launch_bounds__(kWaves * 64, 1) void si_fft_kernel(const SiFftArgs 
       }
     half_wave_sync();
   }
-  store_sums(p.C - 1);
+  store_sums(c_hi - 1);
 }
 
 // frame t = first-half sum of block t + second-half sum of block t + 1 (compute.py:980-990)
@@ -470,7 +472,13 @@ int32_t launch_si_fft(const pds_si_plan *plan, const float *d_signal, const int6
     kern = nw <= 3 ? si_fft_kernel<false, 3> : nw <= 5 ? si_fft_kernel<false, 5> : nw <= 8 ? si_fft_kernel<false, 8> : si_fft_kernel<false, kMaxWindowRegs>;
   const int per_wg = plan->fft.big ? kWaves : 2 * kWaves;  // transforms per workgroup
   PDS_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-  dim3 grid((unsigned)((transforms + per_wg - 1) / per_wg), (unsigned)B);
+  // few workgroups (one utterance, a streaming call): the filters are dealt to several workgroups per stretch, each
+  // repeating the stretch's forward transform -- 1 / c_per_group more work for a pass of filters in parallel
+  const int64_t wgs = (transforms + per_wg - 1) / per_wg * B;
+  const int want = (int)std::min<int64_t>(8, std::max<int64_t>(1, 2 * plan->fft.num_cus / std::max<int64_t>(1, wgs)));
+  p.c_per_group = (p.C + want - 1) / want;
+  const unsigned groups = (unsigned)((p.C + p.c_per_group - 1) / p.c_per_group);
+  dim3 grid((unsigned)((transforms + per_wg - 1) / per_wg), (unsigned)B, groups);
   hipLaunchKernelGGL(kern, grid, dim3(kWaves * 64), smem, (hipStream_t)stream, p);
   PDS_HIP(hipGetLastError());
   const int64_t items = max_frames * d.num_coeffs;
