@@ -20,16 +20,26 @@ __all__ = ["PinnedStaging", "MAX_BYTES"]
 MAX_BYTES = 1 << 30        # beyond this a batch takes the pageable path (pinning a GiB costs more than it saves)
 _MIN_BYTES = 1 << 20        # below this the pageable path is as fast
 _THREADS = 8
+_POOL = None
+_POOL_LOCK = threading.Lock()
+
+
+def _pool() -> ThreadPoolExecutor:
+    """One copy pool for the process (not one per computer)"""
+    global _POOL
+    with _POOL_LOCK:
+        if _POOL is None:
+            _POOL = ThreadPoolExecutor(max_workers=_THREADS, thread_name_prefix="pds-pack")
+        return _POOL
 
 
 class PinnedStaging:
-    """Two pinned buffers (grown on demand, reused) and a copy pool; one batch at a time"""
+    """Two pinned buffers (grown on demand, reused); one batch at a time"""
 
     def __init__(self):
         self._lock = threading.Lock()
         self._up = None
         self._down = None
-        self._pool = None
 
     def _buffer(self, which: str, nbytes: int):
         torch = _native.require_device()
@@ -68,9 +78,7 @@ class PinnedStaging:
                 host[int(offsets[b]) : int(offsets[b + 1])] = np.asarray(signals[b]).reshape(-1)
 
         if len(jobs) > 1:
-            if self._pool is None:
-                self._pool = ThreadPoolExecutor(max_workers=_THREADS, thread_name_prefix="pds-pack")
-            list(self._pool.map(copy, jobs))
+            list(_pool().map(copy, jobs))
         else:
             for run in jobs:
                 copy(run)
