@@ -443,8 +443,14 @@ def main():
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
         if args.backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
-        else:
+            try:
+                dist.init_process_group("nccl", device_id=dev)
+            except Exception as exc:  # RCCL unusable on this node: the hot path has no collective, so time it anyway
+                # (barrier and the reductions of the timings over gloo; the optional gather leg is skipped)
+                print("bench.py: RCCL process group failed (%r): falling back to gloo for the barriers" % (exc,),
+                      file=sys.stderr, flush=True)
+                args.backend = "gloo"
+        if args.backend != "nccl":
             dist.init_process_group("gloo")
             args.no_gather = True
     red_dev = dev if args.backend == "nccl" else torch.device("cpu")
