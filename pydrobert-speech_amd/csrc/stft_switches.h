@@ -157,3 +157,16 @@ extern unsigned long long *g_stamp_buf;  // (stft_fast.hip: pds_debug_set_stamp_
 #ifndef PDS_MIRROR_REBASE
 #define PDS_MIRROR_REBASE 1
 #endif
+
+// float64 samples WITH fused pre-emphasis on the geometries without the 16-byte pair loads (8 / 32 / 64 lanes per
+// frame): 8-byte values loaded per batch (a row takes two: predecessor and sample); 0: row by row, as the compiler
+// schedules it (which is what the kernels without pre-emphasis keep).
+#ifndef PDS_F64_ROW_BATCH
+#define PDS_F64_ROW_BATCH 12
+#endif
+
+// Fused pre-emphasis of float32 / int16 samples on the 8-lane geometries (N = 128 / 256: 8 kHz audio) with DPP
+// operands too (two selects + two multiply-adds per row instead of a second load); 0: predecessors are loaded.
+#ifndef PDS_PREEMPH_DPP8
+#define PDS_PREEMPH_DPP8 1
+#endif
